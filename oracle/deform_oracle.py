@@ -1,0 +1,111 @@
+"""CPU restatement of the reference's per-Gaussian deformation step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Restates, in explicit index arithmetic (no F.grid_sample, no nn.Module), what the reference computes in
+  scene/hexplane.py:19-20   normalize_aabb            (aabb[0]=max, aabb[1]=min: the axis is flipped)
+  scene/hexplane.py:21-46   grid_sample_wrapper       (bilinear, align_corners=True, padding_mode='border')
+  scene/hexplane.py:73-106  interpolate_ms_features   (product over the 6 planes, concat over levels)
+  scene/deformation.py:67-83,97-148  query_time / forward_dynamic (trunk Linear, 5 heads, out = in + delta)
+  gaussian_renderer/__init__.py:97-99  exp / normalize / sigmoid activations (optional here)
+Parameters are consumed by their reference `state_dict()` names, so a reference
+`deform_network.state_dict()` can be fed straight in.  PINNED: tests/test_oracle_deform.py checks this file
+against the reference modules imported from /root/reference and against the golden
+vectors in tests/golden/ generated from them by tests/golden/make_deform_golden.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import itertools
+
+import torch
+import torch.nn.functional as F
+
+PLANE_PAIRS = list(itertools.combinations(range(4), 2))  # (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)
+HEADS = [("pos_deform", "no_dx", 3), ("scales_deform", "no_ds", 3), ("rotations_deform", "no_dr", 4),
+         ("opacity_deform", "no_do", 1), ("shs_deform", "no_dshs", 48)]
+
+
+def _bilinear_border(plane, x, y):
+    """plane [1,C,Hy,Wx]; x,y in normalised [-1,1] coords ([N]); returns [N,C].
+    pixel = ((coord+1)/2)*(size-1), clamped to [0,size-1]; the clamp has zero gradient outside (0,size-1)."""
+    _, C, Hy, Wx = plane.shape
+
+    def unnorm(c, size):
+        p = ((c + 1.0) / 2.0) * (size - 1)
+        inside = (p > 0) & (p < size - 1)
+        p = torch.where(inside, p, p.detach().clamp(0, size - 1))
+        return p
+
+    ix, iy = unnorm(x, Wx), unnorm(y, Hy)
+    x0, y0 = torch.floor(ix.detach()), torch.floor(iy.detach())
+    wx1, wy1 = ix - x0, iy - y0
+    wx0, wy0 = 1.0 - wx1, 1.0 - wy1
+    x0i, y0i = x0.long(), y0.long()
+    x1i, y1i = (x0i + 1).clamp(max=Wx - 1), (y0i + 1).clamp(max=Hy - 1)
+    p = plane[0].permute(1, 2, 0)  # [Hy,Wx,C]
+    v00, v01 = p[y0i, x0i], p[y0i, x1i]
+    v10, v11 = p[y1i, x0i], p[y1i, x1i]
+    return (v00 * (wx0 * wy0)[:, None] + v01 * (wx1 * wy0)[:, None] + v10 * (wx0 * wy1)[:, None] +
+            v11 * (wx1 * wy1)[:, None])
+
+
+def hexplane_features(sd, xyz, t, n_levels, prefix="deformation_net.grid."):
+    aabb = sd[prefix + "aabb"]
+    pts = (xyz - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0
+    q = torch.cat([pts, t.reshape(-1, 1)], dim=-1)
+    feats = []
+    for lvl in range(n_levels):
+        prod = None
+        for k, (i, j) in enumerate(PLANE_PAIRS):
+            v = _bilinear_border(sd[f"{prefix}grids.{lvl}.{k}"], q[:, i], q[:, j])
+            prod = v if prod is None else prod * v
+        feats.append(prod)
+    return torch.cat(feats, dim=-1)
+
+
+def count_levels(sd, prefix="deformation_net.grid."):
+    n = 0
+    while f"{prefix}grids.{n}.0" in sd:
+        n += 1
+    return n
+
+
+def deform_forward(sd, flags, xyz, scales, rotations, opacity, shs, t, activate=False):
+    """sd: reference state_dict (tensors, may require grad); flags: object with no_dx/no_ds/no_dr/no_do/no_dshs.
+    Returns (means3D, scales, rotations, opacity, shs) like deform_network.forward; with activate=True the
+    scales/rotations/opacity are passed through exp / normalize(eps 1e-12) / sigmoid."""
+    feat = hexplane_features(sd, xyz, t, count_levels(sd))
+    hidden = F.linear(feat, sd["deformation_net.feature_out.0.weight"], sd["deformation_net.feature_out.0.bias"])
+    ins = [xyz, scales, rotations, opacity, shs]
+    outs = []
+    for (name, flag, k), x in zip(HEADS, ins):
+        if getattr(flags, flag):
+            outs.append(x)
+            continue
+        h = F.linear(torch.relu(hidden), sd[f"deformation_net.{name}.1.weight"], sd[f"deformation_net.{name}.1.bias"])
+        d = F.linear(torch.relu(h), sd[f"deformation_net.{name}.3.weight"], sd[f"deformation_net.{name}.3.bias"])
+        outs.append(x + d.reshape(x.shape))
+    pts, sc, rot, op, sh = outs
+    if activate:
+        sc = torch.exp(sc)
+        rot = rot / rot.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        op = torch.sigmoid(op)
+    return pts, sc, rot, op, sh
+
+
+def import_reference_deform_network():
+    """import the reference's own deform_network on CPU (only where /root/reference exists)."""
+    import sys
+    import types
+    REF = "/root/reference"
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    if "scene" not in sys.modules or not hasattr(sys.modules["scene"], "__path__") or \
+            REF + "/scene" not in list(sys.modules["scene"].__path__):
+        pkg = types.ModuleType("scene")
+        pkg.__path__ = [REF + "/scene"]
+        sys.modules["scene"] = pkg
+    if "tkinter" not in sys.modules:
+        tk = types.ModuleType("tkinter")
+        tk.W = "w"
+        sys.modules["tkinter"] = tk
+    from scene.deformation import deform_network
+    return deform_network

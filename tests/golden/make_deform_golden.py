@@ -1,0 +1,51 @@
+"""Generates tests/golden/deform_<cfg>.npz by running the REFERENCE's own deform_network (imported from
+/root/reference per SURVEY.md Appendix E) on seeded inputs.  Run here (the GPU box has no /root/reference):
+    python tests/golden/make_deform_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import deform_oracle as DO  # noqa: E402
+
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+
+def main():
+    deform_network = DO.import_reference_deform_network()
+    for cfg in ("dnerf_bouncingballs", "hypernerf_default", "dynerf_default"):
+        torch.manual_seed(6666)
+        args = synthetic.deform_args(cfg)
+        # keep fixtures small: shrink plane resolution (the arithmetic is resolution-agnostic)
+        args.kplanes_config["resolution"] = [8, 8, 8, 6]
+        net = deform_network(args)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if "grids" in name:
+                    p.add_(0.1 * torch.randn_like(p))
+        n = 96
+        g = synthetic.make_gaussians(n, seed=7)
+        xyz = g["xyz"] * 1.1  # some points outside the aabb -> border clamp
+        net.deformation_net.set_aabb([1.3, 1.3, 1.3], [-1.3, -1.3, -1.3])
+        shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
+        t = torch.rand(n, 1)
+        t[:4] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])
+        with torch.no_grad():
+            out = net(xyz, g["scaling"], g["rotation"], g["opacity"], shs, t)
+        d = {"sd." + k: v.detach().numpy() for k, v in net.state_dict().items()}
+        for k, v in zip(("xyz", "scales", "rot", "opacity", "shs", "t"), (xyz, g["scaling"], g["rotation"], g["opacity"], shs, t)):
+            d["in." + k] = v.numpy()
+        for k, v in zip(("xyz", "scales", "rot", "opacity", "shs"), out):
+            d["out." + k] = v.numpy()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"deform_{cfg}.npz")
+        np.savez_compressed(path, **d)
+        print(path, os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()

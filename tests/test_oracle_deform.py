@@ -1,0 +1,74 @@
+"""Pins oracle/deform_oracle.py against the reference's own modules (imported from /root/reference when present,
+SURVEY.md Appendix E) and against committed golden vectors generated from them (tests/golden/)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import have_reference
+from oracle import deform_oracle as DO
+
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _inputs(n, seed=1):
+    g = synthetic.make_gaussians(n, seed=seed)
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
+    return g["xyz"], g["scaling"], g["rotation"], g["opacity"], shs
+
+
+@pytest.mark.skipif(not have_reference(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("cfg", ["dnerf_bouncingballs", "hypernerf_default", "dynerf_default"])
+def test_matches_reference_modules_fwd_bwd(cfg):
+    deform_network = DO.import_reference_deform_network()
+    torch.manual_seed(6666)
+    args = synthetic.deform_args(cfg)
+    net = deform_network(args)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "grids" in name:
+                p.add_(0.1 * torch.randn_like(p))
+    n = 257
+    xyz, sc, rot, op, shs = [x.clone().requires_grad_(True) for x in _inputs(n)]
+    net.deformation_net.set_aabb(xyz.max(0).values.tolist(), xyz.min(0).values.tolist())
+    t = torch.rand(n, 1)
+    ref = net(xyz, sc, rot, op, shs, t)
+    sd = {k: v for k, v in net.named_parameters()}
+    sd.update({k: v for k, v in net.named_buffers()})
+    ora = DO.deform_forward(sd, args, xyz, sc, rot, op, shs, t)
+    for a, b in zip(ref, ora):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    ws = [torch.randn_like(a) for a in ref]
+    params = [p for p in net.parameters() if p.requires_grad]
+    gr = torch.autograd.grad(sum((a * w).sum() for a, w in zip(ref, ws)), [xyz, sc, rot, op, shs] + params, allow_unused=True)
+    go = torch.autograd.grad(sum((a * w).sum() for a, w in zip(ora, ws)), [xyz, sc, rot, op, shs] + params, allow_unused=True)
+    for a, b in zip(gr, go):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("cfg", ["dnerf_bouncingballs", "hypernerf_default", "dynerf_default"])
+def test_matches_golden(cfg):
+    z = np.load(os.path.join(GOLD, f"deform_{cfg}.npz"))
+    sd = {k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd.")}
+    args = synthetic.deform_args(cfg)
+    ins = [torch.tensor(z["in." + k]) for k in ("xyz", "scales", "rot", "opacity", "shs", "t")]
+    outs = DO.deform_forward(sd, args, *ins)
+    for k, o in zip(("xyz", "scales", "rot", "opacity", "shs"), outs):
+        assert torch.allclose(o, torch.tensor(z["out." + k]), rtol=1e-5, atol=1e-6), k
+
+
+def test_border_and_flip_semantics():
+    # xyz = aabb max maps to -1 (flipped axis) and samples column 0; t is used un-normalised
+    C = 4
+    sd = {"deformation_net.grid.aabb": torch.tensor([[1.0, 1.0, 1.0], [-1.0, -1.0, -1.0]])}
+    for k in range(6):
+        sd[f"deformation_net.grid.grids.0.{k}"] = torch.ones(1, C, 5, 7)
+    ramp = torch.arange(7.0).view(1, 1, 1, 7).expand(1, C, 5, 7).clone()
+    sd["deformation_net.grid.grids.0.0"] = ramp  # plane (x,y): width indexes x
+    f = DO.hexplane_features(sd, torch.tensor([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0], [5.0, 0.0, 0.0]]), torch.zeros(3, 1), 1)
+    assert torch.allclose(f[:, 0], torch.tensor([0.0, 6.0, 0.0]))
