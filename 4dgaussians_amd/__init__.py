@@ -1,0 +1,12 @@
+"""MI355X-native 4D-Gaussian render path (hand-written HIP for gfx950 behind the reference's Python API).
+
+The directory name starts with a digit, so import it by string:
+    fdgs = importlib.import_module("4dgaussians_amd")          (or `import fdgs`, the root-level alias)
+Sub-modules: rasterizer (drop-in for `diff_gaussian_rasterization`), deformation (drop-in `deform_network`),
+renderer (`render()` of gaussian_renderer/__init__.py:18), parallel (frame-parallel driver), synthetic (test scenes).
+The HIP library is loaded lazily on first use and there is no CPU fallback.
+"""
+from . import _lib, rasterizer, synthetic  # noqa: F401
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterizer", "synthetic", "_lib"]

@@ -1,0 +1,380 @@
+// binning.hip -- K2..K5: depth sort of the Gaussians, tile-pair expansion, stable tile sort, tile ranges.
+//
+// MI355X-first restructuring of the reference's binning (InclusiveSum + duplicateWithKeys +
+// cub::DeviceRadixSort over 64-bit (tile|depth) keys + identifyTileRanges).  The 64-bit sort over R pairs is split
+// into two stable LSD radix sorts that give the identical order:
+//   (1) sort the P Gaussians by the fp32 bits of their view depth (4 passes over P 32-bit keys), then
+//   (2) emit the (tile, Gaussian) pairs in that depth order and stable-sort them by tile id only
+//       (ceil(log2(#tiles)/8) = 2 passes over R pairs instead of 6, 8 B per pair instead of 12 B).
+// Ties (equal tile, equal depth) resolve by Gaussian index in both formulations because every pass is stable.
+//
+// Radix pass = wave64 ballot ranking (8 ballots per 64 keys give each lane its rank among equal digits), per-wave
+// digit counters in LDS, keys regrouped by digit in LDS so that the global scatter writes contiguous runs.
+#include "common.h"
+
+namespace fdgs {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---------------------------------------------------------------- single-workgroup scan (1024 threads x 4 items)
+// in-place capable; GATHER: value i = src[idx[i]]
+template <bool GATHER, bool INCLUSIVE>
+__global__ void __launch_bounds__(1024) scan_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                    uint32_t* __restrict__ dst, uint32_t n) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096) {
+        uint32_t v[4];
+        const uint32_t i0 = base + t * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t i = i0 + k;
+            v[k] = 0;
+            if (i < n) v[k] = GATHER ? src[idx[i]] : src[i];
+        }
+        uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = tsum;  // wave inclusive scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t u = __shfl_up(inc, o, 64);
+            if (lane >= (uint32_t)o) inc += u;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) wprefix += (k < (int)w) ? wsum[k] : 0u;
+        const uint32_t carry = carry_s;
+        uint32_t run = carry + wprefix + inc - tsum;  // exclusive prefix of this thread's first item
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t i = i0 + k;
+            uint32_t excl = run;
+            run += v[k];
+            if (i < n) dst[i] = INCLUSIVE ? run : excl;
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = run;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- radix histogram: hist[digit*nblocks + block]
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                                  uint32_t* __restrict__ hist, int nblocks) {
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_CHUNK;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        uint32_t i = base + j * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---------------------------------------------------------------- radix scatter (stable)
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                     const uint32_t* __restrict__ vals_in,
+                                                                     uint32_t* __restrict__ keys_out,
+                                                                     uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                                     const uint32_t* __restrict__ hist, int nblocks) {
+    __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counters
+    __shared__ uint32_t lbase[RADIX];     // start of digit d inside the block-local regrouped array
+    __shared__ uint32_t gbase[RADIX];     // global start of (digit d, this block)
+    __shared__ uint32_t skey[SORT_CHUNK];
+    __shared__ uint32_t sval[SORT_CHUNK];
+    __shared__ uint32_t wtmp[4];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) wcnt[k][t] = 0;
+    __syncthreads();
+    const uint32_t wave_base = blockIdx.x * SORT_CHUNK + w * (SORT_CHUNK / 4);
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+    uint16_t rank[SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const uint32_t i = wave_base + j * 64 + lane;
+        const bool valid = i < n;
+        key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[j] = valid ? vals_in[i] : 0u;
+        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        // lanes that are !valid keep a peers mask that still contains only valid lanes with their digit pattern;
+        // they never use it.
+        const uint32_t below = mbcnt(peers);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        uint32_t basev = 0;
+        if (valid && (int)lane == leader) {
+            basev = wcnt[w][d];
+            wcnt[w][d] = basev + cnt;
+        }
+        basev = __shfl(basev, leader < 0 ? 0 : leader, 64);
+        rank[j] = (uint16_t)(basev + below);
+    }
+    __syncthreads();
+    // per digit (thread t = digit): wave prefixes, block count, block-local exclusive scan, global base
+    {
+        const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        wcnt[0][t] = 0; wcnt[1][t] = c0; wcnt[2][t] = c0 + c1; wcnt[3][t] = c0 + c1 + c2;
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t u = __shfl_up(inc, o, 64);
+            if (lane >= (uint32_t)o) inc += u;
+        }
+        if (lane == 63) wtmp[w] = inc;
+        __syncthreads();
+        uint32_t wp = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wp += (k < (int)w) ? wtmp[k] : 0u;
+        lbase[t] = wp + inc - tot;
+        gbase[t] = hist[(size_t)t * nblocks + blockIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const uint32_t i = wave_base + j * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+            const uint32_t pos = lbase[d] + wcnt[w][d] + rank[j];
+            skey[pos] = key[j];
+            sval[pos] = val[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t block_base = blockIdx.x * SORT_CHUNK;
+    const uint32_t block_n = (n - block_base) < (uint32_t)SORT_CHUNK ? (n - block_base) : (uint32_t)SORT_CHUNK;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++) {
+        const uint32_t li = j * SORT_THREADS + t;
+        if (li < block_n) {
+            const uint32_t k = skey[li];
+            const uint32_t d = (k >> shift) & (RADIX - 1);
+            const uint32_t pos = gbase[d] + (li - lbase[d]);
+            keys_out[pos] = k;
+            vals_out[pos] = sval[li];
+        }
+    }
+}
+
+// LSD radix sort of n (key,val) pairs over bits [0,nbits). Ping-pongs between (k0,v0) and (k1,v1); returns which
+// buffer holds the result (0 or 1) through *result_in.
+int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, int nbits,
+                     uint32_t* hist, int nblocks, int debug, int* result_in) {
+    int cur = 0;
+    if (n > 0) {
+        for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
+            uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
+            uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, hist, nblocks);
+            FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
+            hipLaunchKernelGGL((scan_kernel<false, false>), dim3(1), dim3(1024), 0, stream, hist, (const uint32_t*)nullptr, hist,
+                               (uint32_t)(RADIX * nblocks));
+            FDGS_LAUNCH_CHECK("radix_scan", debug, stream);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist,
+                               nblocks);
+            FDGS_LAUNCH_CHECK("radix_scatter", debug, stream);
+            cur ^= 1;
+        }
+    }
+    *result_in = cur;
+    return FDGS_OK;
+}
+
+// ---------------------------------------------------------------- pair expansion in depth order
+// One workgroup per 256 consecutive depth-sorted Gaussians; every lane then walks the workgroup's pair range with a
+// stride of 256 and finds the owning Gaussian by an 8-step binary search in LDS, so the pair stream is written
+// fully coalesced.
+__global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t* __restrict__ sorted_ids,
+                                                           const uint32_t* __restrict__ offsets_incl,
+                                                           const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect,
+                                                           int gx, uint32_t* __restrict__ pair_tile,
+                                                           uint32_t* __restrict__ pair_gid) {
+    __shared__ uint32_t s_end[256];
+    __shared__ uint32_t s_gid[256];
+    __shared__ uint2 s_rect[256];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 256 + t;
+    uint32_t gid = 0, end = 0, cnt = 0;
+    uint2 rc = make_uint2(0, 0);
+    if (i < P) {
+        gid = sorted_ids[i];
+        end = offsets_incl[i];
+        cnt = tiles[gid];
+        rc = rect[gid];
+    } else {
+        end = offsets_incl[P - 1];
+    }
+    s_end[t] = end; s_gid[t] = gid; s_rect[t] = rc;
+    __syncthreads();
+    const int first = blockIdx.x * 256;
+    const uint32_t start = (first == 0) ? 0u : offsets_incl[first - 1];
+    const uint32_t stop = s_end[255];
+    (void)cnt;
+    for (uint32_t p = start + t; p < stop; p += 256) {
+        // smallest j with s_end[j] > p
+        int lo = 0, hi = 255;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            int mid = (lo + hi) >> 1;
+            if (s_end[mid] > p) hi = mid; else lo = mid + 1;
+        }
+        const int j = lo;
+        const uint2 r = s_rect[j];
+        const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu;
+        const uint32_t w = xmax - xmin;
+        const uint32_t jstart = (j == 0) ? start : s_end[j - 1];
+        const uint32_t local = p - jstart;
+        const uint32_t ty = ymin + local / w, tx = xmin + local % w;
+        pair_tile[p] = ty * (uint32_t)gx + tx;
+        pair_gid[p] = s_gid[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ pair_tile,
+                                                          uint2* __restrict__ ranges) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= R) return;
+    const uint32_t tcur = pair_tile[p];
+    if (p == 0 || pair_tile[p - 1] != tcur) ranges[tcur].x = p;
+    if (p == R - 1 || pair_tile[p + 1] != tcur) ranges[tcur].y = p + 1;
+}
+
+int validate_raster_params(const fdgs_raster_params* p);
+
+}  // namespace fdgs
+
+using namespace fdgs;
+
+extern "C" int fdgs_geom_bytes(int P, size_t* bytes) {
+    FDGS_REQUIRE(P >= 0 && bytes, "bad arguments");
+    *bytes = geom_layout(P).bytes;
+    return FDGS_OK;
+}
+extern "C" int fdgs_img_bytes(int W, int H, size_t* bytes) {
+    FDGS_REQUIRE(W > 0 && H > 0 && bytes, "bad arguments");
+    *bytes = img_layout(W, H).bytes;
+    return FDGS_OK;
+}
+extern "C" int fdgs_binning_bytes(uint32_t R, int W, int H, size_t* bytes) {
+    FDGS_REQUIRE(W > 0 && H > 0 && bytes, "bad arguments");
+    *bytes = bin_layout(R).bytes;
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host) {
+    int rc = validate_raster_params(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(geom && num_rendered_host, "geom/num_rendered_host is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    *num_rendered_host = 0;
+    if (p->P == 0) return FDGS_OK;
+    GeomLayout gl = geom_layout(p->P);
+    // the total was accumulated by preprocess: start its read-back now, sort while it is in flight
+    hipEvent_t ev;
+    FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
+    FDGS_HIP_CHECK(hipEventRecord(ev, stream));
+    int in = 0;
+    rc = radix_sort_pairs(stream, at<uint32_t>(geom, gl.keys0), at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.keys1),
+                          at<uint32_t>(geom, gl.ids1), (uint32_t)p->P, 32, at<uint32_t>(geom, gl.hist), gl.sort_blocks, p->debug,
+                          &in);
+    if (rc) { (void)hipEventDestroy(ev); return rc; }
+    // 4 passes: result is back in buffer 0
+    const uint32_t* sorted_ids = at<uint32_t>(geom, in ? gl.ids1 : gl.ids0);
+    if (in != 0) {  // keep the contract "sorted ids live in ids0" for any pass count
+        FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(geom, gl.ids0), sorted_ids, (size_t)p->P * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    hipLaunchKernelGGL((scan_kernel<true, true>), dim3(1), dim3(1024), 0, stream, at<uint32_t>(geom, gl.tiles),
+                       at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P);
+    {
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) { (void)hipEventDestroy(ev); return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }
+    }
+    hipError_t e = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(FDGS_E_HIP, "%s failed: %s", "hipEventSynchronize", hipGetErrorString(e));
+    if (p->debug) FDGS_HIP_CHECK(hipStreamSynchronize(stream));
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img,
+                             uint32_t R) {
+    int rc = validate_raster_params(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(geom && img && (binning || R == 0), "geom/binning/img is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    ImgLayout il = img_layout(p->W, p->H);
+    FDGS_HIP_CHECK(hipMemsetAsync(at<char>(img, il.ranges), 0, (size_t)il.gx * il.gy * 8, stream));
+    if (p->P == 0 || R == 0) return FDGS_OK;
+    GeomLayout gl = geom_layout(p->P);
+    BinLayout bl = bin_layout(R);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
+                       at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), il.gx,
+                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0));
+    FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
+    int in = 0;
+    rc = radix_sort_pairs(stream, at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.tile1),
+                          at<uint32_t>(binning, bl.gid1), R, tile_bits(il.gx * il.gy), at<uint32_t>(binning, bl.hist), bl.sort_blocks,
+                          p->debug, &in);
+    if (rc) return rc;
+    if (in != 0) {  // odd number of passes: bring the result back to buffer 0 (contract used by render + accessors)
+        FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.tile1), (size_t)R * 4,
+                                      hipMemcpyDeviceToDevice, stream));
+        FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.gid1), (size_t)R * 4,
+                                      hipMemcpyDeviceToDevice, stream));
+    }
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 256)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
+                       at<uint2>(img, il.ranges));
+    FDGS_LAUNCH_CHECK("tile_ranges", p->debug, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_geom_field(void* geom, int P, int which, void** ptr) {
+    FDGS_REQUIRE(geom && ptr && P >= 0, "bad arguments");
+    GeomLayout gl = geom_layout(P);
+    size_t off;
+    switch (which) {
+        case 0: off = gl.depth; break; case 1: off = gl.recA; break; case 2: off = gl.recB; break; case 3: off = gl.recC; break;
+        case 4: off = gl.cov3D; break; case 5: off = gl.tiles; break; case 6: off = gl.clamped; break; case 7: off = gl.rect; break;
+        case 8: off = gl.ids0; break; case 9: off = gl.offsets; break;
+        default: return fail(FDGS_E_INVALID, "%s", "unknown geom field");
+    }
+    *ptr = at<char>(geom, off);
+    return FDGS_OK;
+}
+extern "C" int fdgs_binning_field(void* binning, uint32_t R, int W, int H, int which, void** ptr) {
+    (void)W; (void)H;
+    FDGS_REQUIRE(binning && ptr, "bad arguments");
+    BinLayout bl = bin_layout(R);
+    if (which == 0) *ptr = at<char>(binning, bl.gid0);
+    else if (which == 1) *ptr = at<char>(binning, bl.tile0);
+    else return fail(FDGS_E_INVALID, "%s", "unknown binning field");
+    return FDGS_OK;
+}
+extern "C" int fdgs_img_field(void* img, int W, int H, int which, void** ptr) {
+    FDGS_REQUIRE(img && ptr && W > 0 && H > 0, "bad arguments");
+    ImgLayout il = img_layout(W, H);
+    if (which == 0) *ptr = at<char>(img, il.final_T);
+    else if (which == 1) *ptr = at<char>(img, il.n_contrib);
+    else if (which == 2) *ptr = at<char>(img, il.ranges);
+    else return fail(FDGS_E_INVALID, "%s", "unknown img field");
+    return FDGS_OK;
+}

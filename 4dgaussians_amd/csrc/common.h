@@ -1,0 +1,117 @@
+// common.h -- shared host/device helpers of libfdgs (gfx950 only; no CUDA compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fdgs.h"
+
+namespace fdgs {
+
+// ---- error plumbing (thread-local message, never throws across the ABI) ----
+extern thread_local char g_err[512];
+inline int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+#define FDGS_HIP_CHECK(expr)                                                                       \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fdgs::fail(FDGS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define FDGS_LAUNCH_CHECK(name, dbg, stream)                                                       \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ == hipSuccess && (dbg)) e_ = hipStreamSynchronize(stream);                          \
+        if (e_ != hipSuccess) return fdgs::fail(FDGS_E_HIP, "kernel %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+#define FDGS_REQUIRE(cond, msg)                                        \
+    do {                                                               \
+        if (!(cond)) return fdgs::fail(FDGS_E_INVALID, "%s", msg);    \
+    } while (0)
+
+constexpr int TILE = FDGS_TILE;
+constexpr int TILE_PIX = TILE * TILE;  // 256 threads = 4 wave64 per tile
+constexpr int WAVE = 64;
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- radix sort geometry (binning.hip) ----
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;                       // keys per thread
+constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+// ---- geom buffer layout (struct of arrays, 256-B aligned sections) ----
+struct GeomLayout {
+    size_t depth, recA, recB, recC, cov3D, tiles, clamped, rect, keys0, keys1, ids0, ids1, offsets, hist, total, bytes;
+    int sort_blocks;
+};
+inline GeomLayout geom_layout(int P) {
+    GeomLayout g{};
+    size_t o = 0;
+    size_t n = (size_t)(P > 0 ? P : 1);
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
+    g.total = take(256);  // [0] = total tiles touched (u32), [1] = scan carry scratch
+    g.depth = take(n * 4);
+    g.recA = take(n * 16);
+    g.recB = take(n * 16);
+    g.recC = take(n * 16);
+    g.cov3D = take(n * 24);
+    g.tiles = take(n * 4);
+    g.clamped = take(n * 4);
+    g.rect = take(n * 8);
+    g.keys0 = take(n * 4);
+    g.keys1 = take(n * 4);
+    g.ids0 = take(n * 4);
+    g.ids1 = take(n * 4);
+    g.offsets = take(n * 4);
+    g.sort_blocks = cdiv((long long)n, SORT_CHUNK);
+    g.hist = take(((size_t)RADIX * g.sort_blocks + 1024) * 4);
+    g.bytes = o;
+    return g;
+}
+struct BinLayout {
+    size_t tile0, tile1, gid0, gid1, hist, bytes;
+    int sort_blocks;
+};
+inline BinLayout bin_layout(uint32_t R) {
+    BinLayout b{};
+    size_t o = 0, n = R > 0 ? R : 1;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
+    b.tile0 = take(n * 4); b.tile1 = take(n * 4); b.gid0 = take(n * 4); b.gid1 = take(n * 4);
+    b.sort_blocks = cdiv((long long)n, SORT_CHUNK);
+    b.hist = take(((size_t)RADIX * b.sort_blocks + 1024) * 4);
+    b.bytes = o;
+    return b;
+}
+struct ImgLayout {
+    size_t final_T, n_contrib, ranges, bytes;
+    int gx, gy;
+};
+inline ImgLayout img_layout(int W, int H) {
+    ImgLayout m{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
+    m.gx = (W + TILE - 1) / TILE; m.gy = (H + TILE - 1) / TILE;
+    m.final_T = take((size_t)W * H * 4);
+    m.n_contrib = take((size_t)W * H * 4);
+    m.ranges = take((size_t)m.gx * m.gy * 8);
+    m.bytes = o;
+    return m;
+}
+inline int tile_bits(int ntiles) {
+    int b = 1;
+    while ((1 << b) < ntiles) b++;
+    return b;
+}
+
+template <typename T>
+inline T* at(void* base, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off); }
+template <typename T>
+inline const T* at(const void* base, size_t off) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off); }
+
+}  // namespace fdgs

@@ -1,0 +1,238 @@
+// preprocess.hip -- K1 (per-Gaussian projection forward) and K8 (its backward) for gfx950.
+// One thread per Gaussian, 256-thread workgroups (4 wave64).  Camera constants are read from device memory with
+// wave-uniform (scalar) loads; per-Gaussian state is written as three float4 records so that the blending
+// kernels stage a Gaussian with three 16-byte loads.
+// Replaces preprocessCUDA / computeCov2DCUDA of the un-vendored rasterizer.
+#include "common.h"
+#include "gs_math.h"
+
+namespace fdgs {
+
+__device__ __forceinline__ void load_cam(CamConst& c, const float* __restrict__ view, const float* __restrict__ proj,
+                                         const float* __restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+                                         float scale_mod, int D, int M) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c.view[i] = view[i]; c.proj[i] = proj[i]; }
+    if (campos) { c.campos[0] = campos[0]; c.campos[1] = campos[1]; c.campos[2] = campos[2]; }
+    else { c.campos[0] = c.campos[1] = c.campos[2] = 0.f; }
+    c.tanfovx = tanfovx; c.tanfovy = tanfovy;
+    c.focal_x = (float)W / (2.0f * tanfovx); c.focal_y = (float)H / (2.0f * tanfovy);
+    c.scale_mod = scale_mod; c.W = W; c.H = H;
+    c.gx = (W + TILE - 1) / TILE; c.gy = (H + TILE - 1) / TILE;
+    c.D = D; c.M = M;
+}
+
+struct PreFwdArgs {
+    int P, D, M, W, H;
+    float tanfovx, tanfovy, scale_mod;
+    const float *view, *proj, *campos, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    float* depth; float4 *recA, *recB, *recC; float* cov3D;
+    uint32_t *tiles, *clamped; uint2* rect; uint32_t *keys, *ids, *total;
+    int32_t* radii;
+};
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    CamConst c;
+    load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
+    uint32_t my_tiles = 0;
+    if (i < a.P) {
+        float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
+        float c6[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = a.cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
+            const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+            float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            cov3d_from_scale_rot(s, c.scale_mod, q, c6);
+        }
+        GeoOut g;
+        bool vis = project_gaussian(c, p, c6, &g);
+        int32_t radius = 0;
+        uint32_t key = 0xFFFFFFFFu;
+        if (vis) {
+            float rgb[3];
+            uint32_t cl = 0;
+            if (a.colors_precomp) {
+                rgb[0] = a.colors_precomp[3 * (size_t)i]; rgb[1] = a.colors_precomp[3 * (size_t)i + 1];
+                rgb[2] = a.colors_precomp[3 * (size_t)i + 2];
+            } else {
+                const float* sh = a.shs + (size_t)i * a.M * 3;
+                if (a.M == 16) {
+                    float shl[48];
+                    const float4* s4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        float4 v = s4[k];
+                        shl[4 * k] = v.x; shl[4 * k + 1] = v.y; shl[4 * k + 2] = v.z; shl[4 * k + 3] = v.w;
+                    }
+                    cl = sh_to_rgb(c.D, shl, p, c.campos, rgb);
+                } else {
+                    cl = sh_to_rgb(c.D, sh, p, c.campos, rgb);
+                }
+            }
+            a.depth[i] = g.depth;
+            a.recA[i] = make_float4(g.px, g.py, g.conic[0], g.conic[1]);
+            a.recB[i] = make_float4(g.conic[2], a.opacities[i], g.depth, 0.f);
+            a.recC[i] = make_float4(rgb[0], rgb[1], rgb[2], 0.f);
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)i + k] = c6[k];
+            a.clamped[i] = cl;
+            a.rect[i] = make_uint2(g.rect_min, g.rect_max);
+            radius = g.radius;
+            my_tiles = (uint32_t)g.tiles;
+            key = __float_as_uint(g.depth);  // depth > 0.2: the raw bits order like the value
+        }
+        a.tiles[i] = my_tiles;
+        a.radii[i] = radius;
+        a.keys[i] = key;
+        a.ids[i] = (uint32_t)i;
+    }
+    uint32_t s = wave_sum_u32(my_tiles);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.total, s);
+}
+
+struct PreBwdArgs {
+    int P, D, M, W, H;
+    float tanfovx, tanfovy, scale_mod;
+    const float *view, *proj, *campos, *means3D, *shs, *scales, *rotations;
+    int has_cov_precomp;
+    const float* cov3D; const uint32_t *tiles, *clamped;
+    float* dL_dmeans2D;          // in: xy in pixel units (raw sums); out: NDC units
+    const float4* conic_depth;   // dconic xx, xy(half), yy, ddepth
+    const float* dL_dcolors;
+    float *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drot, *dL_dcov3D;
+};
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.P) return;
+    if (a.tiles[i] == 0) return;
+    CamConst c;
+    load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
+    float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
+    float gx = a.dL_dmeans2D[3 * (size_t)i] * 0.5f * (float)a.W;
+    float gy = a.dL_dmeans2D[3 * (size_t)i + 1] * 0.5f * (float)a.H;
+    a.dL_dmeans2D[3 * (size_t)i] = gx;
+    a.dL_dmeans2D[3 * (size_t)i + 1] = gy;
+    const float4 cd = a.conic_depth[i];
+    float dconic[3] = {cd.x, cd.y, cd.z};
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov6[6];
+    project_bwd(c, p, c6, dconic, cd.w, gx, gy, dmean, dcov6);
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dcov6[k];
+    if (a.shs) {
+        const float* sh = a.shs + (size_t)i * a.M * 3;
+        float drgb[3] = {a.dL_dcolors[3 * (size_t)i], a.dL_dcolors[3 * (size_t)i + 1], a.dL_dcolors[3 * (size_t)i + 2]};
+        float dsh[48];
+        sh_bwd(c.D, sh, p, c.campos, a.clamped[i], drgb, dsh, dmean);
+        int nc = (c.D + 1) * (c.D + 1);
+        float* out = a.dL_dsh + (size_t)i * a.M * 3;
+        for (int k = 0; k < nc * 3; k++) out[k] = dsh[k];
+    }
+    a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
+    a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+    if (!a.has_cov_precomp) {
+        float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+        float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        float ds[3], dq[4];
+        cov3d_bwd(s, c.scale_mod, q, dcov6, ds, dq);
+        a.dL_dscales[3 * (size_t)i] = ds[0]; a.dL_dscales[3 * (size_t)i + 1] = ds[1]; a.dL_dscales[3 * (size_t)i + 2] = ds[2];
+        reinterpret_cast<float4*>(a.dL_drot)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ view, uint8_t* present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float z = view[2] * means3D[3 * (size_t)i] + view[6] * means3D[3 * (size_t)i + 1] + view[10] * means3D[3 * (size_t)i + 2] + view[14];
+    present[i] = z > FDGS_NEAR_CULL ? 1 : 0;
+}
+
+int validate_raster_params(const fdgs_raster_params* p) {
+    FDGS_REQUIRE(p != nullptr, "params is NULL");
+    FDGS_REQUIRE(p->P >= 0 && p->W > 0 && p->H > 0, "bad P/W/H");
+    FDGS_REQUIRE(p->sh_degree >= 0 && p->sh_degree <= 3, "sh_degree must be 0..3");
+    FDGS_REQUIRE((p->shs != nullptr) != (p->colors_precomp != nullptr) || p->P == 0,
+                 "Please provide excatly one of either SHs or precomputed colors!");
+    FDGS_REQUIRE((((p->scales != nullptr) && (p->rotations != nullptr)) != (p->cov3D_precomp != nullptr)) || p->P == 0,
+                 "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    FDGS_REQUIRE(((p->scales != nullptr) == (p->rotations != nullptr)) || p->P == 0, "scales and rotations come as a pair");
+    if (p->shs) {
+        FDGS_REQUIRE(p->sh_coeffs >= (p->sh_degree + 1) * (p->sh_degree + 1) && p->sh_coeffs <= FDGS_SH_COEFFS,
+                     "sh_coeffs must cover the active degree and be <= 16");
+    }
+    FDGS_REQUIRE(p->bg && p->viewmatrix && p->projmatrix && (p->campos || !p->shs), "camera pointers missing");
+    FDGS_REQUIRE((p->W + TILE - 1) / TILE < 65536 && (p->H + TILE - 1) / TILE < 65536, "image too large");
+    return FDGS_OK;
+}
+
+}  // namespace fdgs
+
+using namespace fdgs;
+
+extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, void* geom, int32_t* radii) {
+    int rc = validate_raster_params(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(geom && (radii || p->P == 0), "geom/radii is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomLayout gl = geom_layout(p->P);
+    FDGS_HIP_CHECK(hipMemsetAsync(at<char>(geom, gl.total), 0, 256, stream));
+    if (p->P == 0) return FDGS_OK;
+    PreFwdArgs a{};
+    a.P = p->P; a.D = p->sh_degree; a.M = p->sh_coeffs; a.W = p->W; a.H = p->H;
+    a.tanfovx = p->tanfovx; a.tanfovy = p->tanfovy; a.scale_mod = p->scale_modifier;
+    a.view = p->viewmatrix; a.proj = p->projmatrix; a.campos = p->campos; a.means3D = p->means3D; a.shs = p->shs;
+    a.colors_precomp = p->colors_precomp; a.opacities = p->opacities; a.scales = p->scales; a.rotations = p->rotations;
+    a.cov3D_precomp = p->cov3D_precomp;
+    a.depth = at<float>(geom, gl.depth); a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB);
+    a.recC = at<float4>(geom, gl.recC); a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles);
+    a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
+    a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a);
+    FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
+    return FDGS_OK;
+}
+
+// called from fdgs_raster_bwd (render.hip)
+int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, const void* geom,
+                               const fdgs_raster_grads* g) {
+    if (p->P == 0) return FDGS_OK;
+    GeomLayout gl = geom_layout(p->P);
+    PreBwdArgs a{};
+    a.P = p->P; a.D = p->sh_degree; a.M = p->sh_coeffs; a.W = p->W; a.H = p->H;
+    a.tanfovx = p->tanfovx; a.tanfovy = p->tanfovy; a.scale_mod = p->scale_modifier;
+    a.view = p->viewmatrix; a.proj = p->projmatrix; a.campos = p->campos; a.means3D = p->means3D; a.shs = p->shs;
+    a.scales = p->scales; a.rotations = p->rotations; a.has_cov_precomp = p->cov3D_precomp != nullptr;
+    a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles); a.clamped = at<uint32_t>(geom, gl.clamped);
+    a.dL_dmeans2D = g->dL_dmeans2D; a.conic_depth = reinterpret_cast<const float4*>(g->scratch_conic);
+    a.dL_dcolors = g->dL_dcolors; a.dL_dmeans3D = g->dL_dmeans3D; a.dL_dsh = g->dL_dsh; a.dL_dscales = g->dL_dscales;
+    a.dL_drot = g->dL_drotations; a.dL_dcov3D = g->dL_dcov3D;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a);
+    FDGS_LAUNCH_CHECK("preprocess_bwd", p->debug, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_mark_visible(void* stream_, int P, const float* means3D, const float* viewmatrix,
+                                 const float* projmatrix, uint8_t* present) {
+    (void)projmatrix;
+    FDGS_REQUIRE(P >= 0 && (P == 0 || (means3D && viewmatrix && present)), "bad arguments");
+    if (P == 0) return FDGS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(cdiv(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    FDGS_LAUNCH_CHECK("mark_visible", 0, stream);
+    return FDGS_OK;
+}

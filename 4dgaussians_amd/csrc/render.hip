@@ -1,0 +1,301 @@
+// render.hip -- K6 (front-to-back alpha blending) and K7 (its backward) for gfx950.
+//
+// One 256-thread workgroup (4 wave64) per 16x16-pixel tile, one pixel per lane; a wave covers a 16x4 pixel strip.
+// Tiles are handed to XCDs in contiguous bands (workgroup b lands on XCD b%8 -> band b%8) so that the per-Gaussian
+// records a band keeps re-reading stay in that XCD's 4 MiB L2.
+// Per round the workgroup stages 256 list entries (3 x float4 per Gaussian) in LDS; the inner loop reads them with
+// wave-uniform (broadcast) ds_read_b128.
+// Backward: each lane recomputes alpha back-to-front; the per-Gaussian sums over the 64 pixels of a wave are formed
+// with DPP butterflies inside the 16-lane rows plus v_permlane16_swap / v_permlane32_swap across rows (no LDS
+// traffic), skipped entirely when no lane of the wave is hit; the four waves meet in a 10-float LDS slot per staged
+// Gaussian and the tile issues ONE set of global float atomics per (tile, Gaussian).
+// Replaces renderCUDA forward/backward of the un-vendored rasterizer (Appendix B.3/B.4).
+#include "common.h"
+#include "gs_math.h"
+
+namespace fdgs {
+
+__device__ __forceinline__ int tile_of_block(int b, int ntiles) {
+    const int chunk = (ntiles + 7) >> 3;
+    const int tile = (b & 7) * chunk + (b >> 3);
+    return ((b >> 3) < chunk && tile < ntiles) ? tile : -1;
+}
+
+struct RenderArgs {
+    int W, H, gx, gy;
+    const uint2* ranges; const uint32_t* pair_gid;
+    const float4 *recA, *recB, *recC;
+    const float* bg;
+    float* final_T; uint32_t* n_contrib;
+    float *out_color, *out_depth;
+};
+
+__global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
+    const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
+    if (tile < 0) return;
+    __shared__ float4 sA[256], sB[256], sC[256];
+    const int t = threadIdx.x;
+    const int x = (tile % a.gx) * TILE + (t & 15), y = (tile / a.gx) * TILE + (t >> 4);
+    const bool inside = x < a.W && y < a.H;
+    const float pxf = (float)x, pyf = (float)y;
+    const uint2 range = a.ranges[tile];
+    int toDo = (int)(range.y - range.x);
+    const int rounds = (toDo + 255) / 256;
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t contributor = 0, last = 0;
+    for (int r = 0; r < rounds; r++, toDo -= 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const int e = r * 256 + t;
+        if (range.x + e < range.y) {
+            const uint32_t gid = a.pair_gid[range.x + e];
+            sA[t] = a.recA[gid]; sB[t] = a.recB[gid]; sC[t] = a.recC[gid];
+        }
+        __syncthreads();
+        const int lim = toDo < 256 ? toDo : 256;
+        for (int j = 0; !done && j < lim; j++) {
+            contributor++;
+            const float4 A = sA[j];
+            const float4 B = sB[j];
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(FDGS_ALPHA_MAX, B.y * __expf(power));
+            if (alpha < FDGS_ALPHA_MIN) continue;
+            const float test_T = T * (1.0f - alpha);
+            if (test_T < FDGS_T_STOP) { done = true; continue; }
+            const float4 Cc = sC[j];
+            const float w = alpha * T;
+            C0 += Cc.x * w; C1 += Cc.y * w; C2 += Cc.z * w; Dp += B.z * w;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)y * a.W + x, hw = (size_t)a.H * a.W;
+        a.final_T[pix] = T; a.n_contrib[pix] = last;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[hw + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * hw + pix] = C2 + T * a.bg[2];
+        a.out_depth[pix] = Dp;
+    }
+}
+
+// ---- wave64 all-reduce (sum): DPP inside rows, permlane swaps across rows; every lane ends with the total ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  : xor 1
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  : xor 2
+    v += dpp_f<0x141>(v);  // row_half_mirror      : other quad of the 8
+    v += dpp_f<0x140>(v);  // row_mirror           : other half of the 16
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+
+struct RenderBwdArgs {
+    int W, H, gx, gy;
+    const uint2* ranges; const uint32_t* pair_gid;
+    const float4 *recA, *recB, *recC;
+    const float* bg;
+    const float* final_T; const uint32_t* n_contrib;
+    const float *dL_dcolor, *dL_ddepth;
+    float* dL_dmean2D;   // [P,3] pixel units (x,y)
+    float* conic_depth;  // [P,4] dconic xx, xy(half), yy ; ddepth
+    float* dL_dopacity;  // [P]
+    float* dL_dcolors;   // [P,3]
+};
+
+constexpr int ACC_STRIDE = 257;  // 10 rows of 256 sums, odd row stride => conflict-free LDS atomics and flush
+
+__global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
+    const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
+    if (tile < 0) return;
+    __shared__ float4 sA[256], sB[256], sC[256];
+    __shared__ uint32_t sGid[256];
+    __shared__ float sAcc[10 * ACC_STRIDE];
+    __shared__ uint32_t sMax[4];
+    const int t = threadIdx.x, lane = t & 63;
+    const int x = (tile % a.gx) * TILE + (t & 15), y = (tile / a.gx) * TILE + (t >> 4);
+    const bool inside = x < a.W && y < a.H;
+    const float pxf = (float)x, pyf = (float)y;
+    const size_t pix = (size_t)y * a.W + x, hw = (size_t)a.H * a.W;
+    const uint2 range = a.ranges[tile];
+    const float T_final = inside ? a.final_T[pix] : 0.f;
+    const uint32_t last_contributor = inside ? a.n_contrib[pix] : 0u;
+    // the tile only ever needs the first max(n_contrib) entries of its list
+    {
+        uint32_t m = last_contributor;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+        if (lane == 0) sMax[t >> 6] = m;
+    }
+    __syncthreads();
+    uint32_t mx = sMax[0]; mx = sMax[1] > mx ? sMax[1] : mx; mx = sMax[2] > mx ? sMax[2] : mx; mx = sMax[3] > mx ? sMax[3] : mx;
+    const int toDo = (int)mx;
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f;
+    if (inside) {
+        dp0 = a.dL_dcolor[pix]; dp1 = a.dL_dcolor[hw + pix]; dp2 = a.dL_dcolor[2 * hw + pix];
+        if (a.dL_ddepth) ddep = a.dL_ddepth[pix];
+    }
+    const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
+    float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
+    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
+    const int rounds = (toDo + 255) / 256;
+    for (int r = 0; r < rounds; r++) {
+        const int e = toDo - 1 - (r * 256 + t);  // list entry (0-based from the front) staged by this thread
+        if (e >= 0) {
+            const uint32_t gid = a.pair_gid[range.x + e];
+            sGid[t] = gid; sA[t] = a.recA[gid]; sB[t] = a.recB[gid]; sC[t] = a.recC[gid];
+        }
+#pragma unroll
+        for (int k = 0; k < 10; k++) sAcc[k * ACC_STRIDE + t] = 0.f;
+        __syncthreads();
+        const int rem = toDo - r * 256;
+        const int lim = rem < 256 ? rem : 256;
+        for (int j = 0; j < lim; j++) {
+            const uint32_t ej = (uint32_t)(toDo - 1 - (r * 256 + j));
+            const float4 A = sA[j];
+            const float4 B = sB[j];
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(FDGS_ALPHA_MAX, B.y * G);
+            const bool valid = (ej < last_contributor) && !(power > 0.0f) && !(alpha < FDGS_ALPHA_MIN);
+            if (!__any(valid)) continue;
+            float g_mx = 0.f, g_my = 0.f, g_cxx = 0.f, g_cxy = 0.f, g_cyy = 0.f, g_op = 0.f, g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f,
+                  g_d = 0.f;
+            if (valid) {
+                const float4 Cc = sC[j];
+                T = T / (1.0f - alpha);
+                const float w = alpha * T;
+                float dL_dalpha;
+                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = Cc.x;
+                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = Cc.y;
+                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = Cc.z;
+                accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = B.z;
+                dL_dalpha = (Cc.x - acc0) * dp0 + (Cc.y - acc1) * dp1 + (Cc.z - acc2) * dp2 + (B.z - accd) * ddep;
+                g_c0 = w * dp0; g_c1 = w * dp1; g_c2 = w * dp2; g_d = w * ddep;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
+                const float dL_dG = B.y * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * A.z - gdy * A.w;
+                const float dG_ddely = -gdy * B.x - gdx * A.w;
+                g_mx = dL_dG * dG_ddelx; g_my = dL_dG * dG_ddely;
+                g_cxx = -0.5f * gdx * dx * dL_dG; g_cxy = -0.5f * gdx * dy * dL_dG; g_cyy = -0.5f * gdy * dy * dL_dG;
+                g_op = G * dL_dalpha;
+            }
+            g_mx = wave_allsum(g_mx); g_my = wave_allsum(g_my);
+            g_cxx = wave_allsum(g_cxx); g_cxy = wave_allsum(g_cxy); g_cyy = wave_allsum(g_cyy);
+            g_op = wave_allsum(g_op);
+            g_c0 = wave_allsum(g_c0); g_c1 = wave_allsum(g_c1); g_c2 = wave_allsum(g_c2);
+            g_d = wave_allsum(g_d);
+            float v = g_mx;
+            v = lane == 1 ? g_my : v; v = lane == 2 ? g_cxx : v; v = lane == 3 ? g_cxy : v; v = lane == 4 ? g_cyy : v;
+            v = lane == 5 ? g_op : v; v = lane == 6 ? g_c0 : v; v = lane == 7 ? g_c1 : v; v = lane == 8 ? g_c2 : v;
+            v = lane == 9 ? g_d : v;
+            if (lane < 10) atomicAdd(&sAcc[lane * ACC_STRIDE + j], v);
+        }
+        __syncthreads();
+        if (e >= 0) {
+            float s[10];
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < 10; k++) { s[k] = sAcc[k * ACC_STRIDE + t]; nz = nz || (s[k] != 0.f); }
+            if (nz) {
+                const uint32_t gid = sGid[t];
+                atomicAdd(&a.dL_dmean2D[3 * (size_t)gid], s[0]);
+                atomicAdd(&a.dL_dmean2D[3 * (size_t)gid + 1], s[1]);
+                atomicAdd(&a.conic_depth[4 * (size_t)gid], s[2]);
+                atomicAdd(&a.conic_depth[4 * (size_t)gid + 1], s[3]);
+                atomicAdd(&a.conic_depth[4 * (size_t)gid + 2], s[4]);
+                atomicAdd(&a.dL_dopacity[gid], s[5]);
+                atomicAdd(&a.dL_dcolors[3 * (size_t)gid], s[6]);
+                atomicAdd(&a.dL_dcolors[3 * (size_t)gid + 1], s[7]);
+                atomicAdd(&a.dL_dcolors[3 * (size_t)gid + 2], s[8]);
+                if (a.dL_ddepth) atomicAdd(&a.conic_depth[4 * (size_t)gid + 3], s[9]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int validate_raster_params(const fdgs_raster_params* p);
+
+}  // namespace fdgs
+
+int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, const void* geom, const fdgs_raster_grads* g);
+
+using namespace fdgs;
+
+extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const void* geom, const void* binning, void* img,
+                               uint32_t R, float* out_color, float* out_depth) {
+    int rc = validate_raster_params(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(geom && img && out_color && out_depth && (binning || R == 0), "NULL buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    GeomLayout gl = geom_layout(p->P);
+    BinLayout bl = bin_layout(R);
+    ImgLayout il = img_layout(p->W, p->H);
+    RenderArgs a{};
+    a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy;
+    a.ranges = at<uint2>(img, il.ranges); a.pair_gid = binning ? at<uint32_t>(binning, bl.gid0) : nullptr;
+    a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
+    a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
+    a.out_color = out_color; a.out_depth = out_depth;
+    const int ntiles = il.gx * il.gy;
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+    FDGS_LAUNCH_CHECK("render_fwd", p->debug, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const void* geom, const void* binning,
+                               const void* img, uint32_t R, const fdgs_raster_grads* g) {
+    int rc = validate_raster_params(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(g && geom && img && (binning || R == 0), "NULL buffer");
+    FDGS_REQUIRE(g->dL_dcolor && g->dL_dmeans2D && g->dL_dmeans3D && g->dL_dopacity && g->dL_dcolors && g->dL_dcov3D &&
+                     g->scratch_conic, "required gradient buffer is NULL");
+    FDGS_REQUIRE(!p->shs || g->dL_dsh, "dL_dsh required when shs is given");
+    FDGS_REQUIRE(p->cov3D_precomp || (g->dL_dscales && g->dL_drotations), "dL_dscales/dL_drotations required");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t P = (size_t)p->P;
+    if (P == 0) return FDGS_OK;
+    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dmeans2D, 0, P * 12, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dmeans3D, 0, P * 12, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dopacity, 0, P * 4, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcolors, 0, P * 12, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcov3D, 0, P * 24, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_conic, 0, P * 16, stream));
+    if (g->dL_dsh) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dsh, 0, P * (size_t)p->sh_coeffs * 12, stream));
+    if (g->dL_dscales) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dscales, 0, P * 12, stream));
+    if (g->dL_drotations) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_drotations, 0, P * 16, stream));
+    GeomLayout gl = geom_layout(p->P);
+    BinLayout bl = bin_layout(R);
+    ImgLayout il = img_layout(p->W, p->H);
+    if (R > 0) {
+        RenderBwdArgs a{};
+        a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy;
+        a.ranges = at<uint2>(img, il.ranges); a.pair_gid = at<uint32_t>(binning, bl.gid0);
+        a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
+        a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
+        a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
+        a.dL_dmean2D = g->dL_dmeans2D; a.conic_depth = g->scratch_conic; a.dL_dopacity = g->dL_dopacity;
+        a.dL_dcolors = g->dL_dcolors;
+        const int ntiles = il.gx * il.gy;
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+        FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);
+    }
+    return fdgs_launch_preprocess_bwd(stream, p, geom, g);
+}

@@ -1,0 +1,194 @@
+"""Drop-in for the python package `diff_gaussian_rasterization` of the reference's rasterizer submodule.
+
+Mirrors what the reference imports and calls at gaussian_renderer/__init__.py:14,38-58,120-128,
+merge_many_4dgs.py:33,85-135 and scene/dataset_readers.py:485-508:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+                                  projmatrix, sh_degree, campos, prefiltered, debug)      # plain picklable NamedTuple
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                                        rotations=None, cov3D_precomp=None) -> (color [3,H,W], radii [P] int32,
+                                                                                depth [1,H,W])
+    GaussianRasterizer.markVisible(positions) -> bool [P]
+
+All arithmetic runs in libfdgs.so (hand-written HIP for gfx950) through the C-ABI of include/fdgs.h; PyTorch only
+supplies device memory, the current HIP stream and autograd bookkeeping.  There is no CPU fallback.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import RasterGrads, RasterParams, check, ptr, stream_ptr
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+_pinned = {}
+
+
+def _pinned_u32(device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _pinned:
+        _pinned[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return _pinned[key]
+
+
+def _f32(t, device):
+    if t is None:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+class RasterState:
+    """Buffers one forward pass leaves behind for its backward (the reference's geom/binning/img buffers)."""
+    __slots__ = ("params", "geom", "binning", "img", "num_rendered", "keep")
+
+
+def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp):
+    """Runs stages 1-4 of include/fdgs.h. Returns (color, radii, depth, state)."""
+    L = _lib.lib()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise _lib.FdgsError("the rasterizer runs on the GPU only (tensors must live on a HIP device)")
+    means3D = _f32(means3D, dev)
+    P = means3D.shape[0]
+    H, W = int(settings.image_height), int(settings.image_width)
+    shs, colors_precomp = _f32(_none_if_empty(shs), dev), _f32(_none_if_empty(colors_precomp), dev)
+    scales, rotations = _f32(_none_if_empty(scales), dev), _f32(_none_if_empty(rotations), dev)
+    cov3D_precomp, opacities = _f32(_none_if_empty(cov3D_precomp), dev), _f32(opacities, dev)
+    bg, view = _f32(settings.bg, dev), _f32(settings.viewmatrix, dev)
+    proj, campos = _f32(settings.projmatrix, dev), _f32(settings.campos, dev)
+    if (shs is None) == (colors_precomp is None) and P > 0:
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        if P > 0:
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+    p = RasterParams()
+    p.P, p.sh_degree, p.W, p.H = P, int(settings.sh_degree), W, H
+    p.sh_coeffs = 0 if shs is None else int(shs.numel() // max(P, 1) // 3)
+    p.tanfovx, p.tanfovy, p.scale_modifier = float(settings.tanfovx), float(settings.tanfovy), float(settings.scale_modifier)
+    p.prefiltered, p.debug = int(bool(settings.prefiltered)), int(bool(settings.debug))
+    p.bg, p.viewmatrix, p.projmatrix, p.campos = ptr(bg), ptr(view), ptr(proj), ptr(campos)
+    p.means3D, p.shs, p.colors_precomp, p.opacities = ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities)
+    p.scales, p.rotations, p.cov3D_precomp = ptr(scales), ptr(rotations), ptr(cov3D_precomp)
+    nbytes = _lib.c_size_t()
+    check(L.fdgs_geom_bytes(P, nbytes))
+    geom = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    check(L.fdgs_img_bytes(W, H, nbytes))
+    img = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    st = stream_ptr()
+    check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
+    host = _pinned_u32(dev)
+    check(L.fdgs_bin_prepare(st, p, ptr(geom), _lib.c_void_p(host.data_ptr())))
+    R = int(host.item()) & 0xFFFFFFFF
+    check(L.fdgs_binning_bytes(R, W, H, nbytes))
+    binning = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    check(L.fdgs_bin_sort(st, p, ptr(geom), ptr(binning), ptr(img), R))
+    check(L.fdgs_render_fwd(st, p, ptr(geom), ptr(binning), ptr(img), R, ptr(color), ptr(depth)))
+    state = RasterState()
+    state.params, state.geom, state.binning, state.img, state.num_rendered = p, geom, binning, img, R
+    state.keep = (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, bg, view, proj, campos)
+    return color, radii, depth, state
+
+
+def rasterize_backward(state, grad_color, grad_depth=None):
+    """Backward of rasterize_forward. Returns dict of gradients (None where the input was absent)."""
+    L = _lib.lib()
+    p = state.params
+    means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp = state.keep[:7]
+    dev, P = means3D.device, p.P
+    g = RasterGrads()
+    grad_color = _f32(grad_color, dev)
+    grad_depth = _f32(grad_depth, dev)
+    out = dict(means2D=torch.empty(P, 3, device=dev), means3D=torch.empty(P, 3, device=dev),
+               opacities=torch.empty(P, 1, device=dev), colors=torch.empty(P, 3, device=dev),
+               cov3D=torch.empty(P, 6, device=dev),
+               shs=None if shs is None else torch.empty(P, p.sh_coeffs, 3, device=dev),
+               scales=None if scales is None else torch.empty(P, 3, device=dev),
+               rotations=None if rotations is None else torch.empty(P, 4, device=dev))
+    scratch = torch.empty(P, 4, device=dev)
+    g.dL_dcolor, g.dL_ddepth = ptr(grad_color), ptr(grad_depth)
+    g.dL_dmeans2D, g.dL_dmeans3D, g.dL_dopacity = ptr(out["means2D"]), ptr(out["means3D"]), ptr(out["opacities"])
+    g.dL_dcolors, g.dL_dsh, g.dL_dscales = ptr(out["colors"]), ptr(out["shs"]), ptr(out["scales"])
+    g.dL_drotations, g.dL_dcov3D, g.scratch_conic = ptr(out["rotations"]), ptr(out["cov3D"]), ptr(scratch)
+    check(L.fdgs_raster_bwd(stream_ptr(), p, ptr(state.geom), ptr(state.binning), ptr(state.img), state.num_rendered, g))
+    return out
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        color, radii, depth, state = rasterize_forward(raster_settings, means3D, sh, colors_precomp, opacities, scales,
+                                                       rotations, cov3Ds_precomp)
+        ctx.state = state
+        ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
+                   scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
+        ctx.shapes = (opacities.shape, None if sh is None else sh.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth):
+        g = rasterize_backward(ctx.state, grad_color, grad_depth)
+        had_sh, had_col, had_scale, had_cov = ctx.had
+        op_shape, sh_shape = ctx.shapes
+        return (g["means3D"], g["means2D"], g["shs"].reshape(sh_shape) if had_sh else None, g["colors"] if had_col else None,
+                g["opacities"].reshape(op_shape), g["scales"] if had_scale else None, g["rotations"] if had_scale else None,
+                g["cov3D"] if had_cov else None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        L = _lib.lib()
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32(positions, positions.device)
+            out = torch.empty(pos.shape[0], dtype=torch.uint8, device=pos.device)
+            check(L.fdgs_mark_visible(stream_ptr(), pos.shape[0], ptr(pos), ptr(_f32(rs.viewmatrix, pos.device)),
+                                      ptr(_f32(rs.projmatrix, pos.device)), ptr(out)))
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

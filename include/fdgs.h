@@ -1,0 +1,205 @@
+/*
+ * fdgs.h -- C-ABI of the MI355X-native 4D-Gaussian render path (libfdgs.so, built by hipcc for gfx950).
+ *
+ * Drop-in boundary.  The reference binds its rasterizer through the pybind module
+ * `diff_gaussian_rasterization._C` of the un-vendored submodule named at .gitmodules:5-7 of the reference
+ * (call sites gaussian_renderer/__init__.py:14,38-58,120-128; merge_many_4dgs.py:33,85-135;
+ * scene/dataset_readers.py:485-508), and its deformation step through the PyTorch modules
+ * scene/deformation.py:161-216 + scene/hexplane.py:109-183.  The entry points below are what a binding of this
+ * path needs instead: plain pointers and sizes, an explicit hipStream_t (passed as void*), every buffer owned and
+ * allocated by the caller, no torch types, no exceptions across the ABI.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FDGS_E_* code otherwise; fdgs_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - all device pointers are float32 unless stated; "opt" pointers may be NULL;
+ *   - matrices are the reference's transposed 4x4s (scene/cameras.py:59-63): flat index m[4*col+row];
+ *   - no function synchronises the device except fdgs_bin_prepare (the single num_rendered read-back that the
+ *     reference's rasterizer also performs) and the *_debug_sync helpers;
+ *   - functions are re-entrant per stream; one host thread per stream.
+ */
+#ifndef FDGS_H
+#define FDGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDGS_OK 0
+#define FDGS_E_INVALID (-1) /* bad argument / unsupported configuration */
+#define FDGS_E_HIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define FDGS_E_NOGPU (-3)   /* no gfx950 device visible */
+
+#define FDGS_TILE 16         /* tile edge in pixels (BLOCK_X = BLOCK_Y of the reference rasterizer) */
+#define FDGS_SH_COEFFS 16    /* max SH coefficients per channel (degree 3) */
+
+const char* fdgs_last_error(void);
+/* ABI version of this header; bump on any signature change. */
+int fdgs_abi_version(void);
+/* Name (gcnArchName) of device `dev` into buf; FDGS_E_NOGPU if none. */
+int fdgs_device_arch(int dev, char* buf, size_t buflen);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Rasterizer: replaces _C.rasterize_gaussians / _C.rasterize_gaussians_backward / _C.mark_visible
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Scratch sizes in bytes. geom: per-Gaussian state (kept for backward); img: per-pixel + per-tile state (kept for
+ * backward); binning: sorted (tile, Gaussian) lists for `num_rendered` pairs (kept for backward). */
+int fdgs_geom_bytes(int P, size_t* bytes);
+int fdgs_img_bytes(int W, int H, size_t* bytes);
+int fdgs_binning_bytes(uint32_t num_rendered, int W, int H, size_t* bytes);
+
+typedef struct fdgs_raster_params {
+    int P;                  /* number of Gaussians */
+    int sh_degree;          /* active degree 0..3 */
+    int sh_coeffs;          /* coefficients per channel actually stored per Gaussian (M, <=16) */
+    int W, H;               /* image size in pixels */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int prefiltered;        /* accepted for API parity; ignored like the reference's non-debug path */
+    int debug;              /* nonzero: synchronise + check errors after every kernel */
+    const float* bg;        /* [3] device */
+    const float* viewmatrix;/* [16] device */
+    const float* projmatrix;/* [16] device */
+    const float* campos;    /* [3] device */
+    const float* means3D;   /* [P,3] */
+    const float* shs;       /* opt [P,M,3] (exactly one of shs / colors_precomp) */
+    const float* colors_precomp; /* opt [P,3] */
+    const float* opacities; /* [P] */
+    const float* scales;    /* opt [P,3] (scales+rotations xor cov3D_precomp) */
+    const float* rotations; /* opt [P,4] (w,x,y,z), used as given (no normalisation) */
+    const float* cov3D_precomp; /* opt [P,6] */
+} fdgs_raster_params;
+
+/* Stage 1: per-Gaussian projection (frustum cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB).
+ * Writes radii[P] (int32) and fills `geom`. */
+int fdgs_preprocess_fwd(void* stream, const fdgs_raster_params* p, void* geom, int32_t* radii);
+
+/* Stage 2: depth-sorts the Gaussians (LSD radix on the fp32 depth bits), scans tiles_touched in depth order and
+ * reads the total back to the host: *num_rendered_host = number of (tile, Gaussian) pairs.  This is the one
+ * blocking read-back of the path (the reference's rasterizer has the same one). */
+int fdgs_bin_prepare(void* stream, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host);
+
+/* Stage 3: writes the pairs in depth order, stable-sorts them by tile id (LSD radix), finds per-tile ranges. */
+int fdgs_bin_sort(void* stream, const fdgs_raster_params* p, void* geom, void* binning, void* img,
+                  uint32_t num_rendered);
+
+/* Stage 4: front-to-back alpha blending per 16x16 tile. out_color [3,H,W], out_depth [1,H,W]. */
+int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom, const void* binning, void* img,
+                    uint32_t num_rendered, float* out_color, float* out_depth);
+
+typedef struct fdgs_raster_grads {
+    const float* dL_dcolor;  /* [3,H,W] */
+    const float* dL_ddepth;  /* opt [1,H,W] */
+    /* outputs, all written (zero-filled first) by fdgs_raster_bwd */
+    float* dL_dmeans2D;      /* [P,3]: x,y in NDC units, z = 0 (the reference's viewspace_points.grad) */
+    float* dL_dmeans3D;      /* [P,3] */
+    float* dL_dopacity;      /* [P] */
+    float* dL_dcolors;       /* [P,3] gradient of the blended per-Gaussian rgb (== dL/dcolors_precomp) */
+    float* dL_dsh;           /* opt [P,M,3] (required when shs was given) */
+    float* dL_dscales;       /* opt [P,3] */
+    float* dL_drotations;    /* opt [P,4] */
+    float* dL_dcov3D;        /* [P,6] */
+    /* scratch owned by the caller, [P,4] floats each */
+    float* scratch_conic;    /* dL/dconic (xx, xy/2-convention, yy) + dL/ddepth in .w */
+} fdgs_raster_grads;
+
+/* Backward of stages 4 and 1 (back-to-front blending gradients, then per-Gaussian chain rule). */
+int fdgs_raster_bwd(void* stream, const fdgs_raster_params* p, const void* geom, const void* binning,
+                    const void* img, uint32_t num_rendered, const fdgs_raster_grads* g);
+
+/* Frustum test only (replaces _C.mark_visible): present[P] (uint8) = 1 where p_view.z > 0.2. */
+int fdgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present);
+
+/* Test/diagnostic access to geom fields (device pointers into `geom`):
+ * 0 depth f32[P]; 1 recA float4[P] (x,y,conic.xx,conic.xy); 2 recB float4[P] (conic.yy,opacity,depth,0);
+ * 3 recC float4[P] (r,g,b,0); 4 cov3D f32[P,6]; 5 tiles_touched u32[P]; 6 clamped u32[P] (bit c = channel c);
+ * 7 rect u32[P,2] (xmin|ymin<<16, xmax|ymax<<16); 8 sorted Gaussian ids u32[P]; 9 point_offsets u32[P] (inclusive,
+ * depth order). */
+int fdgs_geom_field(void* geom, int P, int which, void** ptr);
+/* 0 sorted pair Gaussian ids u32[R]; 1 sorted pair tile ids u32[R]. */
+int fdgs_binning_field(void* binning, uint32_t num_rendered, int W, int H, int which, void** ptr);
+/* 0 final_T f32[H*W]; 1 n_contrib u32[H*W]; 2 ranges u32[ntiles,2]. */
+int fdgs_img_field(void* img, int W, int H, int which, void** ptr);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Deformation field: replaces deform_network.forward (scene/deformation.py:185-212) + the activations of
+ * gaussian_renderer/__init__.py:97-99 when `activate` is set.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+#define FDGS_MAX_LEVELS 4
+#define FDGS_HEAD_POS 0
+#define FDGS_HEAD_SCALE 1
+#define FDGS_HEAD_ROT 2
+#define FDGS_HEAD_OPACITY 3
+#define FDGS_HEAD_SHS 4
+#define FDGS_NUM_HEADS 5
+
+typedef struct fdgs_deform_params {
+    int N;                 /* Gaussians */
+    int C;                 /* features per plane (output_coordinate_dim: 16 or 32) */
+    int L;                 /* levels (len(multires) <= 4) */
+    int W;                 /* net_width (64 or 128) */
+    int head_on[FDGS_NUM_HEADS]; /* 1 = head active (not no_dx / no_ds / no_dr / no_do / no_dshs) */
+    int activate;          /* 1: outputs are exp(scale), normalize(rot), sigmoid(opacity) */
+    int res[FDGS_MAX_LEVELS][4]; /* per level: resolution of axes x,y,z,t */
+    /* planes: channel-LAST device arrays [res_j][res_i][C] for pair k=(i,j) in order (0,1),(0,2),(0,3),(1,2),(1,3),(2,3) */
+    const float* planes[FDGS_MAX_LEVELS][6];
+    float aabb[6];         /* aabb[0..2] = "max" row, aabb[3..5] = "min" row of the reference's HexPlaneField.aabb */
+    const float* w0; const float* b0;               /* feature_out.0: [W, C*L], [W] */
+    const float* w1[FDGS_NUM_HEADS]; const float* b1[FDGS_NUM_HEADS]; /* <head>.1: [W,W],[W] */
+    const float* w2[FDGS_NUM_HEADS]; const float* b2[FDGS_NUM_HEADS]; /* <head>.3: [k,W],[k], k = 3,3,4,1,48 */
+    /* per-Gaussian inputs */
+    const float* xyz;      /* [N,3] */
+    const float* scales;   /* [N,3] log-scales */
+    const float* rotations;/* [N,4] */
+    const float* opacity;  /* [N,1] logits */
+    const float* shs_dc;   /* [N,1,3]  (features_dc) */
+    const float* shs_rest; /* [N,15,3] (features_rest) */
+    const float* time;     /* [N] per-Gaussian time, or NULL to use time_scalar for every Gaussian */
+    float time_scalar;
+} fdgs_deform_params;
+
+typedef struct fdgs_deform_out {
+    float* xyz;       /* [N,3] */
+    float* scales;    /* [N,3] */
+    float* rotations; /* [N,4] */
+    float* opacity;   /* [N,1] */
+    float* shs;       /* [N,16,3] */
+} fdgs_deform_out;
+
+int fdgs_deform_fwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_out* out);
+
+typedef struct fdgs_deform_grads {
+    /* incoming gradients w.r.t. the outputs of fdgs_deform_fwd (same `activate` setting); any may be NULL (=0) */
+    const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs;
+    /* forward outputs (needed when activate=1 for the activation Jacobians) */
+    const float* out_scales; const float* out_rotations; const float* out_opacity;
+    /* outgoing gradients; ACCUMULATED into (+=): the caller zero-fills.  Any may be NULL (skipped). */
+    float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity; float* d_shs_dc; float* d_shs_rest;
+    float* d_planes[FDGS_MAX_LEVELS][6]; /* channel-last like `planes` */
+    float* d_w0; float* d_b0;
+    float* d_w1[FDGS_NUM_HEADS]; float* d_b1[FDGS_NUM_HEADS];
+    float* d_w2[FDGS_NUM_HEADS]; float* d_b2[FDGS_NUM_HEADS];
+    /* scratch owned by the caller, fdgs_deform_bwd_scratch_bytes() bytes */
+    void* scratch;
+} fdgs_deform_grads;
+
+int fdgs_deform_bwd_scratch_bytes(const fdgs_deform_params* p, size_t* bytes);
+int fdgs_deform_bwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_grads* g);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Loss-side helper for the frame-parallel driver: accumulates [sum|a-b|, sum (a-b)^2, n] into acc[3] (device,
+ * caller zero-fills) and optionally writes dL/da = sign(a-b)*scale.  (utils/loss_utils.py:20-21, image_utils.py:17-38)
+ * ---------------------------------------------------------------------------------------------------------- */
+int fdgs_l1_stats(void* stream, size_t n, const float* a, const float* b, float grad_scale, float* grad_out_opt,
+                  float* acc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDGS_H */
