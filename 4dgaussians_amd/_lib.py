@@ -23,7 +23,7 @@ class RasterParams(Structure):
 class RasterGrads(Structure):
     _fields_ = [("dL_dcolor", c_void_p), ("dL_ddepth", c_void_p), ("dL_dmeans2D", c_void_p), ("dL_dmeans3D", c_void_p),
                 ("dL_dopacity", c_void_p), ("dL_dcolors", c_void_p), ("dL_dsh", c_void_p), ("dL_dscales", c_void_p),
-                ("dL_drotations", c_void_p), ("dL_dcov3D", c_void_p), ("scratch_conic", c_void_p)]
+                ("dL_drotations", c_void_p), ("dL_dcov3D", c_void_p), ("scratch_acc", c_void_p)]
 
 
 class DeformParams(Structure):
@@ -36,13 +36,14 @@ class DeformParams(Structure):
 
 
 class DeformOut(Structure):
-    _fields_ = [("xyz", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("opacity", c_void_p), ("shs", c_void_p)]
+    _fields_ = [("xyz", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("opacity", c_void_p), ("shs", c_void_p),
+                ("rot_norm", c_void_p)]
 
 
 class DeformGrads(Structure):
     _fields_ = [("g_xyz", c_void_p), ("g_scales", c_void_p), ("g_rotations", c_void_p), ("g_opacity", c_void_p),
                 ("g_shs", c_void_p), ("out_scales", c_void_p), ("out_rotations", c_void_p), ("out_opacity", c_void_p),
-                ("d_xyz", c_void_p), ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p),
+                ("rot_norm", c_void_p), ("d_xyz", c_void_p), ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p),
                 ("d_shs_dc", c_void_p), ("d_shs_rest", c_void_p), ("d_planes", (c_void_p * 6) * MAX_LEVELS),
                 ("d_w0", c_void_p), ("d_b0", c_void_p), ("d_w1", c_void_p * NUM_HEADS), ("d_b1", c_void_p * NUM_HEADS),
                 ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p)]

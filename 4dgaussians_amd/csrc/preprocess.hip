@@ -106,9 +106,8 @@ struct PreBwdArgs {
     const float *view, *proj, *campos, *means3D, *shs, *scales, *rotations;
     int has_cov_precomp;
     const float* cov3D; const uint32_t *tiles, *clamped;
-    float* dL_dmeans2D;          // in: xy in pixel units (raw sums); out: NDC units
-    const float4* conic_depth;   // dconic xx, xy(half), yy, ddepth
-    const float* dL_dcolors;
+    const float* gacc;           // [P,16] packed sums written by render_bwd (layout in render.hip)
+    float *dL_dmeans2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drot, *dL_dcov3D;
 };
 
@@ -122,19 +121,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
     float c6[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
-    float gx = a.dL_dmeans2D[3 * (size_t)i] * 0.5f * (float)a.W;
-    float gy = a.dL_dmeans2D[3 * (size_t)i + 1] * 0.5f * (float)a.H;
+    const float4* ga = reinterpret_cast<const float4*>(a.gacc + 16 * (size_t)i);
+    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    // mean2D gradient is handed back in NDC units (d pix / d ndc = W/2, H/2), like the reference's viewspace grad
+    float gx = g0.x * 0.5f * (float)a.W, gy = g0.y * 0.5f * (float)a.H;
     a.dL_dmeans2D[3 * (size_t)i] = gx;
     a.dL_dmeans2D[3 * (size_t)i + 1] = gy;
-    const float4 cd = a.conic_depth[i];
-    float dconic[3] = {cd.x, cd.y, cd.z};
+    a.dL_dopacity[i] = g1.y;
+    float drgb[3] = {g1.z, g1.w, g2.x};
+    a.dL_dcolors[3 * (size_t)i] = drgb[0]; a.dL_dcolors[3 * (size_t)i + 1] = drgb[1]; a.dL_dcolors[3 * (size_t)i + 2] = drgb[2];
+    float dconic[3] = {g0.z, g0.w, g1.x};
     float dmean[3] = {0.f, 0.f, 0.f}, dcov6[6];
-    project_bwd(c, p, c6, dconic, cd.w, gx, gy, dmean, dcov6);
+    project_bwd(c, p, c6, dconic, g2.y, gx, gy, dmean, dcov6);
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dcov6[k];
     if (a.shs) {
         const float* sh = a.shs + (size_t)i * a.M * 3;
-        float drgb[3] = {a.dL_dcolors[3 * (size_t)i], a.dL_dcolors[3 * (size_t)i + 1], a.dL_dcolors[3 * (size_t)i + 2]};
         float dsh[48];
         sh_bwd(c.D, sh, p, c.campos, a.clamped[i], drgb, dsh, dmean);
         int nc = (c.D + 1) * (c.D + 1);
@@ -218,7 +220,7 @@ int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, 
     a.view = p->viewmatrix; a.proj = p->projmatrix; a.campos = p->campos; a.means3D = p->means3D; a.shs = p->shs;
     a.scales = p->scales; a.rotations = p->rotations; a.has_cov_precomp = p->cov3D_precomp != nullptr;
     a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles); a.clamped = at<uint32_t>(geom, gl.clamped);
-    a.dL_dmeans2D = g->dL_dmeans2D; a.conic_depth = reinterpret_cast<const float4*>(g->scratch_conic);
+    a.dL_dmeans2D = g->dL_dmeans2D; a.gacc = g->scratch_acc; a.dL_dopacity = g->dL_dopacity;
     a.dL_dcolors = g->dL_dcolors; a.dL_dmeans3D = g->dL_dmeans3D; a.dL_dsh = g->dL_dsh; a.dL_dscales = g->dL_dscales;
     a.dL_drot = g->dL_drotations; a.dL_dcov3D = g->dL_dcov3D;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a);

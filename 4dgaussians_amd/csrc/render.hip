@@ -8,7 +8,7 @@
 // Backward: each lane recomputes alpha back-to-front; the per-Gaussian sums over the 64 pixels of a wave are formed
 // with DPP butterflies inside the 16-lane rows plus v_permlane16_swap / v_permlane32_swap across rows (no LDS
 // traffic), skipped entirely when no lane of the wave is hit; the four waves meet in a 10-float LDS slot per staged
-// Gaussian and the tile issues ONE set of global float atomics per (tile, Gaussian).
+// Gaussian and the tile issues ONE 64-byte atomic line-op per (tile, Gaussian) into a packed [P,16] gradient array.
 // Replaces renderCUDA forward/backward of the un-vendored rasterizer (Appendix B.3/B.4).
 #include "common.h"
 #include "gs_math.h"
@@ -109,10 +109,8 @@ struct RenderBwdArgs {
     const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float *dL_dcolor, *dL_ddepth;
-    float* dL_dmean2D;   // [P,3] pixel units (x,y)
-    float* conic_depth;  // [P,4] dconic xx, xy(half), yy ; ddepth
-    float* dL_dopacity;  // [P]
-    float* dL_dcolors;   // [P,3]
+    float* gacc;  // [P,16] per-Gaussian gradient line: 0,1 mean2D (pixel units) | 2,3,4 conic xx,xy(half),yy | 5 opacity |
+                  // 6,7,8 rgb | 9 depth | 10..15 unused.  One 64-B line per Gaussian => one atomic line-op per (tile,Gaussian)
 };
 
 constexpr int ACC_STRIDE = 257;  // 10 rows of 256 sums, odd row stride => conflict-free LDS atomics and flush
@@ -208,23 +206,17 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
             if (lane < 10) atomicAdd(&sAcc[lane * ACC_STRIDE + j], v);
         }
         __syncthreads();
-        if (e >= 0) {
-            float s[10];
-            bool nz = false;
-#pragma unroll
-            for (int k = 0; k < 10; k++) { s[k] = sAcc[k * ACC_STRIDE + t]; nz = nz || (s[k] != 0.f); }
-            if (nz) {
-                const uint32_t gid = sGid[t];
-                atomicAdd(&a.dL_dmean2D[3 * (size_t)gid], s[0]);
-                atomicAdd(&a.dL_dmean2D[3 * (size_t)gid + 1], s[1]);
-                atomicAdd(&a.conic_depth[4 * (size_t)gid], s[2]);
-                atomicAdd(&a.conic_depth[4 * (size_t)gid + 1], s[3]);
-                atomicAdd(&a.conic_depth[4 * (size_t)gid + 2], s[4]);
-                atomicAdd(&a.dL_dopacity[gid], s[5]);
-                atomicAdd(&a.dL_dcolors[3 * (size_t)gid], s[6]);
-                atomicAdd(&a.dL_dcolors[3 * (size_t)gid + 1], s[7]);
-                atomicAdd(&a.dL_dcolors[3 * (size_t)gid + 2], s[8]);
-                if (a.dL_ddepth) atomicAdd(&a.conic_depth[4 * (size_t)gid + 3], s[9]);
+        // flush: 16 lanes own the 16-float gradient line of one staged Gaussian, so every atomic instruction covers four
+        // whole 64-byte lines (measured: scattered float atomics cost ~1 line-op each at ~20 G line-ops/s on MI355X)
+        {
+            const int wv = t >> 6, sub = lane & 15;
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int jj = wv * 64 + i * 4 + (lane >> 4);
+                if (jj < lim) {
+                    const float v = sub < 10 ? sAcc[sub * ACC_STRIDE + jj] : 0.f;
+                    if (v != 0.f) atomicAdd(&a.gacc[(size_t)sGid[jj] * 16 + sub], v);
+                }
             }
         }
         __syncthreads();
@@ -266,7 +258,7 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     if (rc) return rc;
     FDGS_REQUIRE(g && geom && img && (binning || R == 0), "NULL buffer");
     FDGS_REQUIRE(g->dL_dcolor && g->dL_dmeans2D && g->dL_dmeans3D && g->dL_dopacity && g->dL_dcolors && g->dL_dcov3D &&
-                     g->scratch_conic, "required gradient buffer is NULL");
+                     g->scratch_acc, "required gradient buffer is NULL");
     FDGS_REQUIRE(!p->shs || g->dL_dsh, "dL_dsh required when shs is given");
     FDGS_REQUIRE(p->cov3D_precomp || (g->dL_dscales && g->dL_drotations), "dL_dscales/dL_drotations required");
     hipStream_t stream = (hipStream_t)stream_;
@@ -277,7 +269,7 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dopacity, 0, P * 4, stream));
     FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcolors, 0, P * 12, stream));
     FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcov3D, 0, P * 24, stream));
-    FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_conic, 0, P * 16, stream));
+    FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_acc, 0, P * 64, stream));
     if (g->dL_dsh) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dsh, 0, P * (size_t)p->sh_coeffs * 12, stream));
     if (g->dL_dscales) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dscales, 0, P * 12, stream));
     if (g->dL_drotations) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_drotations, 0, P * 16, stream));
@@ -291,8 +283,7 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
         a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
         a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
-        a.dL_dmean2D = g->dL_dmeans2D; a.conic_depth = g->scratch_conic; a.dL_dopacity = g->dL_dopacity;
-        a.dL_dcolors = g->dL_dcolors;
+        a.gacc = g->scratch_acc;
         const int ntiles = il.gx * il.gy;
         hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
         FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);

@@ -132,11 +132,11 @@ def rasterize_backward(state, grad_color, grad_depth=None):
                shs=None if shs is None else torch.empty(P, p.sh_coeffs, 3, device=dev),
                scales=None if scales is None else torch.empty(P, 3, device=dev),
                rotations=None if rotations is None else torch.empty(P, 4, device=dev))
-    scratch = torch.empty(P, 4, device=dev)
+    scratch = torch.empty(P, 16, device=dev)
     g.dL_dcolor, g.dL_ddepth = ptr(grad_color), ptr(grad_depth)
     g.dL_dmeans2D, g.dL_dmeans3D, g.dL_dopacity = ptr(out["means2D"]), ptr(out["means3D"]), ptr(out["opacities"])
     g.dL_dcolors, g.dL_dsh, g.dL_dscales = ptr(out["colors"]), ptr(out["shs"]), ptr(out["scales"])
-    g.dL_drotations, g.dL_dcov3D, g.scratch_conic = ptr(out["rotations"]), ptr(out["cov3D"]), ptr(scratch)
+    g.dL_drotations, g.dL_dcov3D, g.scratch_acc = ptr(out["rotations"]), ptr(out["cov3D"]), ptr(scratch)
     check(L.fdgs_raster_bwd(stream_ptr(), p, ptr(state.geom), ptr(state.binning), ptr(state.img), state.num_rendered, g))
     return out
 

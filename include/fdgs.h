@@ -103,8 +103,8 @@ typedef struct fdgs_raster_grads {
     float* dL_dscales;       /* opt [P,3] */
     float* dL_drotations;    /* opt [P,4] */
     float* dL_dcov3D;        /* [P,6] */
-    /* scratch owned by the caller, [P,4] floats each */
-    float* scratch_conic;    /* dL/dconic (xx, xy/2-convention, yy) + dL/ddepth in .w */
+    /* scratch owned by the caller: [P,16] floats (one 64-byte gradient line per Gaussian, see render.hip) */
+    float* scratch_acc;
 } fdgs_raster_grads;
 
 /* Backward of stages 4 and 1 (back-to-front blending gradients, then per-Gaussian chain rule). */
@@ -170,6 +170,7 @@ typedef struct fdgs_deform_out {
     float* rotations; /* [N,4] */
     float* opacity;   /* [N,1] */
     float* shs;       /* [N,16,3] */
+    float* rot_norm;  /* opt [N]: |r + dr| before normalisation (written when activate=1; the backward needs it) */
 } fdgs_deform_out;
 
 int fdgs_deform_fwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_out* out);
@@ -178,7 +179,7 @@ typedef struct fdgs_deform_grads {
     /* incoming gradients w.r.t. the outputs of fdgs_deform_fwd (same `activate` setting); any may be NULL (=0) */
     const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs;
     /* forward outputs (needed when activate=1 for the activation Jacobians) */
-    const float* out_scales; const float* out_rotations; const float* out_opacity;
+    const float* out_scales; const float* out_rotations; const float* out_opacity; const float* rot_norm;
     /* outgoing gradients; ACCUMULATED into (+=): the caller zero-fills.  Any may be NULL (skipped). */
     float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity; float* d_shs_dc; float* d_shs_rest;
     float* d_planes[FDGS_MAX_LEVELS][6]; /* channel-last like `planes` */
