@@ -32,7 +32,8 @@ class DeformParams(Structure):
                 ("aabb", c_float * 6), ("w0", c_void_p), ("b0", c_void_p), ("w1", c_void_p * NUM_HEADS),
                 ("b1", c_void_p * NUM_HEADS), ("w2", c_void_p * NUM_HEADS), ("b2", c_void_p * NUM_HEADS),
                 ("xyz", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("opacity", c_void_p),
-                ("shs_dc", c_void_p), ("shs_rest", c_void_p), ("time", c_void_p), ("time_scalar", c_float)]
+                ("shs_dc", c_void_p), ("shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int),
+                ("time", c_void_p), ("time_scalar", c_float)]
 
 
 class DeformOut(Structure):

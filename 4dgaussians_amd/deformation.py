@@ -1,0 +1,311 @@
+"""Drop-in `deform_network` whose forward/backward run as fused HIP kernels (csrc/deform.hip).
+
+Mirrors the module tree and therefore the `state_dict()` keys of the reference:
+  scene/deformation.py:161-216  deform_network  (timenet, deformation_net, *_poc buffers, get_mlp_parameters /
+                                                 get_grid_parameters: optimizer groups are split on the substring "grid")
+  scene/deformation.py:16-160   Deformation     (grid, feature_out, pos/scales/rotations/opacity/shs_deform)
+  scene/hexplane.py:109-183     HexPlaneField   (aabb Parameter [[max],[min]], grids[level][plane] of shape [1,C,res_j,res_i])
+so `deformation.pth` / checkpoints of the reference load unchanged and `GaussianModel.training_setup`'s parameter
+grouping keeps working.  Only `forward` differs: one kernel launch instead of ~60.  Plane parameters are kept in
+channels_last memory (same logical shape and values) because the kernels gather all C channels of a texel at once.
+
+Unsupported reference options raise instead of silently running something else: no_grid, grid_pe, static_mlp,
+empty_voxel, apply_rotation, defor_depth > 1 (none is enabled by any config under arguments/ of the reference).
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import MAX_LEVELS, NUM_HEADS, DeformGrads, DeformOut, DeformParams, check, ptr, stream_ptr
+
+HEAD_NAMES = ("pos_deform", "scales_deform", "rotations_deform", "opacity_deform", "shs_deform")
+HEAD_FLAGS = ("no_dx", "no_ds", "no_dr", "no_do", "no_dshs")
+HEAD_K = (3, 3, 4, 1, 48)
+PLANE_PAIRS = list(itertools.combinations(range(4), 2))
+
+
+class HexPlaneField(nn.Module):
+    def __init__(self, bounds, planeconfig, multires):
+        super().__init__()
+        self.aabb = nn.Parameter(torch.tensor([[bounds] * 3, [-bounds] * 3], dtype=torch.float32), requires_grad=False)
+        self.grid_config = [planeconfig]
+        self.multiscale_res_multipliers = list(multires)
+        self.concat_features = True
+        assert planeconfig["grid_dimensions"] == 2 and planeconfig["input_coordinate_dim"] == 4
+        C = planeconfig["output_coordinate_dim"]
+        base = planeconfig["resolution"]
+        self.grids = nn.ModuleList()
+        self.feat_dim = 0
+        for m in self.multiscale_res_multipliers:
+            reso = [r * m for r in base[:3]] + list(base[3:])
+            level = nn.ParameterList()
+            for (i, j) in PLANE_PAIRS:
+                t = torch.empty(1, C, reso[j], reso[i])
+                if 3 in (i, j):
+                    nn.init.ones_(t)          # time planes start as identity (scene/hexplane.py:64-65)
+                else:
+                    nn.init.uniform_(t, a=0.1, b=0.5)
+                level.append(nn.Parameter(t.contiguous(memory_format=torch.channels_last)))
+            self.grids.append(level)
+            self.feat_dim += C
+
+    @property
+    def get_aabb(self):
+        return self.aabb[0], self.aabb[1]
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.aabb = nn.Parameter(torch.tensor([list(xyz_max), list(xyz_min)], dtype=torch.float32,
+                                              device=self.aabb.device), requires_grad=False)
+
+
+def _head(W, k):
+    return nn.Sequential(nn.ReLU(), nn.Linear(W, W), nn.ReLU(), nn.Linear(W, k))
+
+
+class Deformation(nn.Module):
+    def __init__(self, D=8, W=256, input_ch=27, input_ch_time=9, grid_pe=0, skips=(), args=None):
+        super().__init__()
+        self.D, self.W, self.grid_pe, self.args = D, W, grid_pe, args
+        self.no_grid = args.no_grid
+        for flag in ("no_grid", "empty_voxel", "static_mlp", "apply_rotation"):
+            if getattr(args, flag, False):
+                raise NotImplementedError(f"{flag}=True is not supported by the fused HIP deformation path")
+        if grid_pe not in (0, 1):
+            raise NotImplementedError("grid_pe > 1 is not supported by the fused HIP deformation path")
+        if D > 1:
+            raise NotImplementedError("defor_depth > 1 is not supported by the fused HIP deformation path")
+        self.grid = HexPlaneField(args.bounds, args.kplanes_config, args.multires)
+        self.ratio = 0
+        self.feature_out = nn.Sequential(nn.Linear(self.grid.feat_dim, W))
+        self.pos_deform = _head(W, 3)
+        self.scales_deform = _head(W, 3)
+        self.rotations_deform = _head(W, 4)
+        self.opacity_deform = _head(W, 1)
+        self.shs_deform = _head(W, 48)
+
+    @property
+    def get_aabb(self):
+        return self.grid.get_aabb
+
+    @property
+    def get_empty_ratio(self):
+        return self.ratio
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.grid.set_aabb(xyz_max, xyz_min)
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" not in n]
+
+    def get_grid_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" in n]
+
+
+def _init_linear(m):
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight, gain=1)  # biases keep the PyTorch default (scene/deformation.py:218-224)
+
+
+class deform_network(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        times_ch = 2 * args.timebase_pe + 1
+        self.timenet = nn.Sequential(nn.Linear(times_ch, args.timenet_width), nn.ReLU(),
+                                     nn.Linear(args.timenet_width, args.timenet_output))
+        self.deformation_net = Deformation(W=args.net_width, D=args.defor_depth, input_ch=3 + 3 * args.posebase_pe * 2,
+                                           grid_pe=args.grid_pe, input_ch_time=args.timenet_output, args=args)
+        self.register_buffer("time_poc", torch.FloatTensor([2 ** i for i in range(args.timebase_pe)]))
+        self.register_buffer("pos_poc", torch.FloatTensor([2 ** i for i in range(args.posebase_pe)]))
+        self.register_buffer("rotation_scaling_poc", torch.FloatTensor([2 ** i for i in range(args.scale_rotation_pe)]))
+        self.register_buffer("opacity_poc", torch.FloatTensor([2 ** i for i in range(args.opacity_pe)]))
+        self.args = args
+        self.apply(_init_linear)
+
+    @property
+    def get_aabb(self):
+        return self.deformation_net.get_aabb
+
+    @property
+    def get_empty_ratio(self):
+        return self.deformation_net.get_empty_ratio
+
+    def get_mlp_parameters(self):
+        return self.deformation_net.get_mlp_parameters() + list(self.timenet.parameters())
+
+    def get_grid_parameters(self):
+        return self.deformation_net.get_grid_parameters()
+
+    def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
+        return self.forward_dynamic(point, scales, rotations, opacity, shs, times_sel)
+
+    def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
+        """Module-level API of the reference: raw (pre-activation) outputs (scene/deformation.py:198-212)."""
+        out = deform(self, point, scales, rotations, opacity, shs=shs, time=times_sel, activate=False)
+        return out[0], out[1], out[2], out[3], out[4].reshape(shs.shape)
+
+
+def _head_on(args):
+    return [0 if getattr(args, f) else 1 for f in HEAD_FLAGS]
+
+
+def _collect(net):
+    """Flat, ordered tensor list handed to the autograd Function (must match _DeformFunction.backward)."""
+    dn = net.deformation_net
+    planes = [dn.grid.grids[l][k] for l in range(len(dn.grid.grids)) for k in range(6)]
+    mlp = [dn.feature_out[0].weight, dn.feature_out[0].bias]
+    for name in HEAD_NAMES:
+        seq = getattr(dn, name)
+        mlp += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+    return planes, mlp
+
+
+def deform(net, xyz, scales, rotations, opacity, shs=None, shs_dc=None, shs_rest=None, time=None, activate=False):
+    """Runs the fused deformation.  Either `shs` ([N,16,3]) or the pair (shs_dc [N,1,3], shs_rest [N,15,3]) is given
+    (the pair skips the torch.cat of GaussianModel.get_features, scene/gaussian_model.py:121-124).  `time` is a python
+    float (one frame time for all Gaussians, as render() uses it) or a [N,1] tensor.
+    Returns (means3D, scales, rotations, opacity, shs [N,16,3]); with activate=True scales/rotations/opacity have had
+    exp / normalize / sigmoid applied (gaussian_renderer/__init__.py:97-99)."""
+    planes, mlp = _collect(net)
+    dn = net.deformation_net
+    cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
+               head_on=_head_on(dn.args), activate=bool(activate))
+    if isinstance(time, torch.Tensor):
+        t_tensor, t_scalar = time, 0.0
+    else:
+        t_tensor, t_scalar = None, float(time)
+    if shs is not None:
+        a, b = shs, None
+    else:
+        a, b = shs_dc, shs_rest
+    return _DeformFunction.apply(cfg, t_scalar, xyz, scales, rotations, opacity, a, b, t_tensor, dn.grid.aabb, *planes, *mlp)
+
+
+def _cl(p):
+    """channels_last-contiguous view/copy of a plane [1,C,H,W] -> memory [H][W][C]."""
+    return p if p.is_contiguous(memory_format=torch.channels_last) and p.dtype == torch.float32 else \
+        p.float().contiguous(memory_format=torch.channels_last)
+
+
+def _fill_params(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb_host, planes, mlp, keep):
+    p = DeformParams()
+    N = xyz.shape[0]
+    p.N, p.C, p.L, p.W, p.activate = N, cfg["C"], cfg["L"], cfg["W"], int(cfg["activate"])
+    for i in range(NUM_HEADS):
+        p.head_on[i] = cfg["head_on"][i]
+    for l in range(cfg["L"]):
+        for k, (i, j) in enumerate(PLANE_PAIRS):
+            pl = planes[l * 6 + k]
+            p.planes[l][k] = pl.data_ptr()
+        # axis resolutions of this level from the plane shapes: plane (0,1) is [1,C,res_y,res_x], (2,3) is [1,C,res_t,res_z]
+        p.res[l][0], p.res[l][1] = planes[l * 6 + 0].shape[3], planes[l * 6 + 0].shape[2]
+        p.res[l][2], p.res[l][3] = planes[l * 6 + 5].shape[3], planes[l * 6 + 5].shape[2]
+    for i in range(6):
+        p.aabb[i] = aabb_host[i]
+    p.w0, p.b0 = mlp[0].data_ptr(), mlp[1].data_ptr()
+    for h in range(NUM_HEADS):
+        p.w1[h], p.b1[h] = mlp[2 + 4 * h].data_ptr(), mlp[3 + 4 * h].data_ptr()
+        p.w2[h], p.b2[h] = mlp[4 + 4 * h].data_ptr(), mlp[5 + 4 * h].data_ptr()
+    p.xyz, p.scales, p.rotations, p.opacity = ptr(xyz), ptr(scales), ptr(rotations), ptr(opacity)
+    if sh_b is None:  # one combined [N,16,3] tensor
+        p.shs_dc, p.shs_rest = sh_a.data_ptr(), sh_a.data_ptr() + 12
+        p.shs_dc_stride = p.shs_rest_stride = 48
+    else:
+        p.shs_dc, p.shs_rest, p.shs_dc_stride, p.shs_rest_stride = sh_a.data_ptr(), sh_b.data_ptr(), 3, 45
+    p.time = ptr(t_tensor)
+    p.time_scalar = t_scalar
+    keep.append((xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, planes, mlp))
+    return p
+
+
+_aabb_cache = {}
+
+
+def _aabb_to_host(aabb):
+    """The 6 aabb floats are needed in the kernel-argument struct; cache the host copy per tensor version."""
+    key = (aabb.data_ptr(), aabb._version)
+    v = _aabb_cache.get(key)
+    if v is None:
+        v = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
+        _aabb_cache.clear()
+        _aabb_cache[key] = v
+    return v
+
+
+class _DeformFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, *rest):
+        L = _lib.lib()
+        dev = xyz.device
+        if dev.type != "cuda":
+            raise _lib.FdgsError("the deformation kernels run on the GPU only")
+        nplanes = cfg["L"] * 6
+        planes_in, mlp_in = rest[:nplanes], rest[nplanes:]
+        c = lambda t: None if t is None else t.detach().float().contiguous()
+        xyz_, scales_, rot_, op_ = c(xyz), c(scales), c(rotations), c(opacity)
+        sh_a_, sh_b_ = c(sh_a), c(sh_b)
+        t_ = None if t_tensor is None else c(t_tensor).reshape(-1)
+        planes = [_cl(p.detach()) for p in planes_in]
+        mlp = [c(m) for m in mlp_in]
+        N = xyz_.shape[0]
+        keep = []
+        p = _fill_params(cfg, t_scalar, xyz_, scales_, rot_, op_, sh_a_, sh_b_, t_, _aabb_to_host(aabb), planes, mlp, keep)
+        out = DeformOut()
+        o_xyz, o_sc = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+        o_rot, o_op = torch.empty(N, 4, device=dev), torch.empty(N, 1, device=dev)
+        o_sh = torch.empty(N, 16, 3, device=dev)
+        o_norm = torch.empty(N, device=dev) if cfg["activate"] else None
+        out.xyz, out.scales, out.rotations, out.opacity, out.shs, out.rot_norm = ptr(o_xyz), ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_sh), ptr(o_norm)
+        check(L.fdgs_deform_fwd(stream_ptr(), p, out))
+        ctx.cfg, ctx.t_scalar, ctx.p, ctx.keep = cfg, t_scalar, p, keep
+        ctx.saved = (o_sc, o_rot, o_op, o_norm)
+        ctx.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape,
+                          sh_b=None if sh_b is None else sh_b.shape)
+        ctx.plane_shapes = [tuple(q.shape) for q in planes_in]
+        ctx.needs = ctx.needs_input_grad
+        return o_xyz, o_sc, o_rot, o_op, o_sh
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_sc, g_rot, g_op, g_sh):
+        L = _lib.lib()
+        cfg, p = ctx.cfg, ctx.p
+        xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, planes, mlp = ctx.keep[0]
+        o_sc, o_rot, o_op, o_norm = ctx.saved
+        dev, N = xyz.device, xyz.shape[0]
+        c = lambda t: None if t is None else t.float().contiguous()
+        g = DeformGrads()
+        gx, gs, gr, go, gsh = c(g_xyz), c(g_sc), c(g_rot), c(g_op), c(g_sh)
+        g.g_xyz, g.g_scales, g.g_rotations, g.g_opacity, g.g_shs = ptr(gx), ptr(gs), ptr(gr), ptr(go), ptr(gsh)
+        g.out_scales, g.out_rotations, g.out_opacity, g.rot_norm = ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_norm)
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        d_xyz, d_sc, d_rot, d_op = z(N, 3), z(N, 3), z(N, 4), z(N, 1)
+        if sh_b is None:
+            d_sha, d_shb = z(N, 16, 3), None
+            g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_sha.data_ptr() + 12
+        else:
+            d_sha, d_shb = z(N, 1, 3), z(N, 15, 3)
+            g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_shb.data_ptr()
+        g.d_xyz, g.d_scales, g.d_rotations, g.d_opacity = ptr(d_xyz), ptr(d_sc), ptr(d_rot), ptr(d_op)
+        d_planes = [torch.zeros(s, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+                    for s in ctx.plane_shapes]
+        for l in range(cfg["L"]):
+            for k in range(6):
+                g.d_planes[l][k] = d_planes[l * 6 + k].data_ptr()
+        d_mlp = [torch.zeros_like(m) for m in mlp]
+        g.d_w0, g.d_b0 = d_mlp[0].data_ptr(), d_mlp[1].data_ptr()
+        for h in range(NUM_HEADS):
+            g.d_w1[h], g.d_b1[h] = d_mlp[2 + 4 * h].data_ptr(), d_mlp[3 + 4 * h].data_ptr()
+            g.d_w2[h], g.d_b2[h] = d_mlp[4 + 4 * h].data_ptr(), d_mlp[5 + 4 * h].data_ptr()
+        nbytes = _lib.c_size_t()
+        check(L.fdgs_deform_bwd_scratch_bytes(p, nbytes))
+        scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        g.scratch = ptr(scratch)
+        check(L.fdgs_deform_bwd(stream_ptr(), p, g))
+        for h in range(NUM_HEADS):  # parameters of a disabled head receive no gradient (as under autograd)
+            if not cfg["head_on"][h]:
+                d_mlp[2 + 4 * h:6 + 4 * h] = [None] * 4
+        sh = ctx.shapes
+        return (None, None, d_xyz, d_sc.reshape(sh["scales"]), d_rot.reshape(sh["rot"]), d_op.reshape(sh["op"]),
+                d_sha.reshape(sh["sh_a"]), None if d_shb is None else d_shb.reshape(sh["sh_b"]), None, None,
+                *d_planes, *d_mlp)

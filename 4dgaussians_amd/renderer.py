@@ -1,0 +1,95 @@
+"""Drop-in for `gaussian_renderer.render` of the reference (gaussian_renderer/__init__.py:18-138).
+
+Same signature, same result dict {"render","viewspace_points","visibility_filter","radii","depth"}; honours
+pipe.convert_SHs_python / pipe.compute_cov3D_python / pipe.debug and cam_type == "PanopticSports" exactly where the
+reference does.  When `pc._deformation` is this package's `deform_network`, the fine stage runs as two fused HIP
+stages: deform(+activations, + the cat of features_dc/features_rest) -> rasterize; no `time.repeat(N,1)` tensor, no
+positional-embedding scratch.  With a foreign deformation module (e.g. the reference's own) the module is called as
+the reference calls it and only the rasterizer is replaced.
+"""
+import math
+
+import torch
+
+from . import deformation as _deformation
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _dev(t, device):
+    return t if t.device == device else t.to(device, non_blocking=True)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, stage="fine", cam_type=None):
+    means3D = pc.get_xyz
+    device = means3D.device
+    # gradient sink for the screen-space means (train.py:223-225 reads .grad of this tensor)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    if cam_type != "PanopticSports":
+        tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+        tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+        raster_settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+            viewmatrix=_dev(viewpoint_camera.world_view_transform, device),
+            projmatrix=_dev(viewpoint_camera.full_proj_transform, device), sh_degree=pc.active_sh_degree,
+            campos=_dev(viewpoint_camera.camera_center, device), prefiltered=False, debug=pipe.debug)
+        frame_time = float(viewpoint_camera.time)
+    else:
+        raster_settings = viewpoint_camera["camera"]
+        frame_time = float(viewpoint_camera["time"])
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means2D = screenspace_points
+    opacity = pc._opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc._scaling, pc._rotation
+
+    fused = isinstance(pc._deformation, _deformation.deform_network) and not pipe.compute_cov3D_python
+    if "coarse" in stage:
+        means3D_final, shs_final = means3D, pc.get_features
+        scales_final = None if scales is None else pc.scaling_activation(scales)
+        rotations_final = None if rotations is None else pc.rotation_activation(rotations)
+        opacity_final = pc.opacity_activation(opacity)
+    elif "fine" in stage:
+        if fused:
+            means3D_final, scales_final, rotations_final, opacity_final, shs_final = _deformation.deform(
+                pc._deformation, means3D, scales, rotations, opacity, shs_dc=pc._features_dc, shs_rest=pc._features_rest,
+                time=frame_time, activate=True)
+        else:
+            time = torch.tensor(frame_time).to(device).repeat(means3D.shape[0], 1)
+            means3D_final, scales_final, rotations_final, opacity_final, shs_final = pc._deformation(
+                means3D, scales, rotations, opacity, pc.get_features, time)
+            scales_final = None if scales_final is None else pc.scaling_activation(scales_final)
+            rotations_final = None if rotations_final is None else pc.rotation_activation(rotations_final)
+            opacity_final = pc.opacity_activation(opacity_final)
+    else:
+        raise NotImplementedError
+
+    colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            # python SH path of the reference (gaussian_renderer/__init__.py:106-111): basis polynomial of
+            # utils/sh_utils.py:57-112 evaluated with torch ops, colours handed to the rasterizer precomputed
+            from .sh import eval_sh
+            feats = pc.get_features
+            shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - _dev(viewpoint_camera.camera_center, device).repeat(feats.shape[0], 1)
+            dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+            shs_final = None
+    else:
+        colors_precomp = override_color
+        shs_final = None
+
+    rendered_image, radii, depth = rasterizer(
+        means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp, opacities=opacity_final,
+        scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth}

@@ -136,3 +136,64 @@ def deform_args(name, **overrides):
     base.update(cfg)
     base.update(overrides)
     return Namespace(**base)
+
+
+class SynthModel(torch.nn.Module):
+    """Minimal stand-in for the reference's GaussianModel: exactly the attributes `render()` reads
+    (scene/gaussian_model.py:36-44,108-131): parameters, activations, get_xyz / get_features, the deformation module."""
+
+    def __init__(self, n, deform_cfg="dynerf_default", seed=6666, sh_degree=3, device="cpu", perturb_time_planes=0.1,
+                 deformation=None):
+        super().__init__()
+        from . import deformation as D
+        g = make_gaussians(n, seed=seed, sh_degree=sh_degree)
+        self._xyz = torch.nn.Parameter(g["xyz"])
+        self._scaling = torch.nn.Parameter(g["scaling"])
+        self._rotation = torch.nn.Parameter(g["rotation"])
+        self._opacity = torch.nn.Parameter(g["opacity"])
+        self._features_dc = torch.nn.Parameter(g["features_dc"])
+        self._features_rest = torch.nn.Parameter(g["features_rest"])
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = sh_degree
+        torch.manual_seed(seed)
+        if deformation is None:
+            self._deformation = D.deform_network(deform_args(deform_cfg))
+            gen = torch.Generator().manual_seed(seed + 1)
+            with torch.no_grad():
+                for name, p in self._deformation.named_parameters():
+                    if "grids" in name and perturb_time_planes:
+                        p.add_(perturb_time_planes * torch.randn(p.shape, generator=gen))
+            self._deformation.deformation_net.set_aabb(g["xyz"].max(0).values.tolist(), g["xyz"].min(0).values.tolist())
+        else:
+            self._deformation = deformation
+        self._deformation_table = torch.ones(n, dtype=torch.bool)
+        self.scaling_activation = torch.exp
+        self.rotation_activation = torch.nn.functional.normalize
+        self.opacity_activation = torch.sigmoid
+        self.to(device)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def get_covariance(self, scaling_modifier=1):
+        s = scaling_modifier * torch.exp(self._scaling)
+        q = self._rotation / self._rotation.norm(dim=1, keepdim=True)
+        r, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z),
+                         1 - 2 * (x * x + z * z), 2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x),
+                         1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+        Lm = R * s[:, None, :]
+        S = Lm @ Lm.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+
+
+class PipelineParams:
+    """arguments/__init__.py:66-73 defaults."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False

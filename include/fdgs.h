@@ -158,8 +158,10 @@ typedef struct fdgs_deform_params {
     const float* scales;   /* [N,3] log-scales */
     const float* rotations;/* [N,4] */
     const float* opacity;  /* [N,1] logits */
-    const float* shs_dc;   /* [N,1,3]  (features_dc) */
-    const float* shs_rest; /* [N,15,3] (features_rest) */
+    const float* shs_dc;   /* features_dc:   3 floats per Gaussian at shs_dc[n*shs_dc_stride + m] */
+    const float* shs_rest; /* features_rest: 45 floats per Gaussian at shs_rest[n*shs_rest_stride + m] */
+    int shs_dc_stride;     /* 3 for a separate [N,1,3] tensor; 48 when both point into one [N,16,3] tensor */
+    int shs_rest_stride;   /* 45 for a separate [N,15,3] tensor; 48 (with shs_rest = shs + 3) for a combined one */
     const float* time;     /* [N] per-Gaussian time, or NULL to use time_scalar for every Gaussian */
     float time_scalar;
 } fdgs_deform_params;
@@ -181,7 +183,8 @@ typedef struct fdgs_deform_grads {
     /* forward outputs (needed when activate=1 for the activation Jacobians) */
     const float* out_scales; const float* out_rotations; const float* out_opacity; const float* rot_norm;
     /* outgoing gradients; ACCUMULATED into (+=): the caller zero-fills.  Any may be NULL (skipped). */
-    float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity; float* d_shs_dc; float* d_shs_rest;
+    float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity;
+    float* d_shs_dc; float* d_shs_rest; /* laid out with the strides of the inputs (shs_dc_stride / shs_rest_stride) */
     float* d_planes[FDGS_MAX_LEVELS][6]; /* channel-last like `planes` */
     float* d_w0; float* d_b0;
     float* d_w1[FDGS_NUM_HEADS]; float* d_b1[FDGS_NUM_HEADS];

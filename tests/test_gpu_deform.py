@@ -1,0 +1,164 @@
+"""GPU parity tests of the fused HIP deformation (HexPlane + MLP, fwd + bwd) and of render() end to end, against the
+CPU oracle (which is itself pinned to the reference's modules, tests/test_oracle_deform.py)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deform_oracle as DO
+from oracle.raster_oracle import RasterOracle
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+
+def _fdgs():
+    return importlib.import_module("4dgaussians_amd")
+
+
+def _net_and_inputs(cfg, n, seed, dev, overrides=None):
+    fd = _fdgs()
+    torch.manual_seed(seed)
+    args = synthetic.deform_args(cfg, **(overrides or {}))
+    net = fd.deform_network(args)
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "grids" in name:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    g = synthetic.make_gaussians(n, seed=seed)
+    xyz = g["xyz"] * 1.05  # a few points outside the aabb: border clamp + zero coordinate gradient
+    net.deformation_net.set_aabb([1.3, 1.25, 1.2], [-1.3, -1.2, -1.25])
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
+    t = torch.rand(n, 1, generator=gen)
+    t[: min(4, n)] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])[: min(4, n)]
+    ins = [xyz, g["scaling"], g["rotation"], g["opacity"], shs, t]
+    return args, net, ins
+
+
+CFGS = [("dnerf_bouncingballs", 1000), ("hypernerf_default", 257), ("dynerf_default", 1531),
+        ("dynerf_default", 31)]
+
+
+@pytest.mark.parametrize("cfg,n", CFGS)
+@pytest.mark.parametrize("activate", [False, True])
+def test_deform_forward_backward_parity(cfg, n, activate):
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs(cfg, n, 3, dev)
+    # oracle on CPU with the same state dict
+    sd = {k: v.detach().clone().contiguous().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in net.state_dict().items()}
+    cpu_in = [x.clone().requires_grad_(i < 5) for i, x in enumerate(ins)]
+    ref = DO.deform_forward(sd, args, *cpu_in, activate=activate)
+    net = net.to(dev)
+    gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
+    out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=activate)
+    torch.cuda.synchronize()
+    names = ("xyz", "scales", "rot", "opacity", "shs")
+    for k, a, b in zip(names, out, ref):
+        e = rel_l2(a.detach().cpu().numpy(), b.detach().numpy().reshape(a.shape))
+        assert e < 2e-5, (k, e)
+    gen = torch.Generator().manual_seed(11)
+    ws = [torch.randn(b.shape, generator=gen) for b in ref]
+    loss_ref = sum((a * w).sum() for a, w in zip(ref, ws))
+    params_cpu = [sd[k] for k in sd if sd[k].requires_grad]
+    pnames = [k for k in sd if sd[k].requires_grad]
+    g_ref = torch.autograd.grad(loss_ref, cpu_in[:5] + params_cpu, allow_unused=True)
+    loss = sum((a * w.to(dev).reshape(a.shape)).sum() for a, w in zip(out, ws))
+    params_gpu = [dict(net.named_parameters())[k] for k in pnames]
+    g_gpu = torch.autograd.grad(loss, gpu_in[:5] + params_gpu, allow_unused=True)
+    report = {}
+    for k, a, b in zip(list(names) + pnames, g_gpu, g_ref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, k
+            continue
+        assert a is not None, k
+        report[k] = rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape))
+    worst = sorted(report.items(), key=lambda kv: -kv[1])[:4]
+    print(f"[{cfg} n={n} act={activate}] worst grad rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    for k, v in report.items():
+        assert v < 1e-3, (k, v)
+
+
+def test_module_api_matches_reference_signature_and_scalar_time():
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs("dnerf_bouncingballs", 300, 5, dev)
+    net = net.to(dev)
+    gi = [x.to(dev) for x in ins]
+    gi[5] = torch.full_like(gi[5], 0.37)
+    a = net(gi[0], gi[1], gi[2], gi[3], gi[4], gi[5])
+    b = fd.deformation.deform(net, gi[0], gi[1], gi[2], gi[3], shs=gi[4], time=0.37, activate=False)
+    c = fd.deformation.deform(net, gi[0], gi[1], gi[2], gi[3], shs_dc=gi[4][:, :1].contiguous(), shs_rest=gi[4][:, 1:].contiguous(),
+                              time=0.37, activate=False)
+    assert a[4].shape == (300, 16, 3) and a[3].shape == (300, 1)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y.reshape(x.shape)) and torch.equal(x, z.reshape(x.shape))
+    # disabled heads (no_do / no_dshs in this config) pass their input through unchanged
+    assert torch.equal(a[3], gi[3]) and torch.equal(a[4], gi[4])
+
+
+@pytest.mark.parametrize("cfg,stage", [("dynerf_default", "fine"), ("dnerf_bouncingballs", "fine"), ("dynerf_default", "coarse")])
+def test_render_end_to_end_vs_oracle(cfg, stage):
+    """render() (deform -> activations -> rasterize) against oracle deform -> oracle rasterizer, image and every gradient."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    n, W, H = 4000, 200, 152
+    pc = synthetic.SynthModel(n, cfg, seed=21)
+    cam = synthetic.make_camera(W, H, theta_deg=40.0, time=0.6)
+    with torch.no_grad():
+        pc._scaling.add_(1.0)  # bigger splats so that most pixels are covered
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in pc._deformation.state_dict().items()}
+    leaves = {k: getattr(pc, k).detach().clone().requires_grad_(True) for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
+    if stage == "fine":
+        t = torch.full((n, 1), cam.time)
+        m3, sc, rot, op, sh = DO.deform_forward(sd, pc._deformation.args, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"],
+                                                leaves["_opacity"], shs, t, activate=True)
+    else:
+        m3, sh = leaves["_xyz"], shs
+        sc, op = torch.exp(leaves["_scaling"]), torch.sigmoid(leaves["_opacity"])
+        rot = torch.nn.functional.normalize(leaves["_rotation"])
+    f = lambda x: np.ascontiguousarray(x.detach().numpy())
+    o = RasterOracle(means3D=f(m3), scales=f(sc), rotations=f(rot), opacities=f(op), shs=f(sh), viewmatrix=f(cam.world_view_transform),
+                     projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center), bg=np.zeros(3, np.float32), image_height=H,
+                     image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+    target = np.random.default_rng(0).random(o.color.shape).astype(np.float32)
+    dc = (np.sign(o.color - target) / o.color.size).astype(np.float32)
+    go = o.backward(dc)
+    # chain the oracle rasterizer gradients through the oracle deformation (autograd on CPU)
+    outs = [m3, sc, rot, op, sh]
+    gouts = [torch.tensor(go["means3D"]), torch.tensor(go["scales"]), torch.tensor(go["rotations"]),
+             torch.tensor(go["opacities"]).reshape(op.shape), torch.tensor(go["shs"]).reshape(sh.shape)]
+    wanted = list(leaves.values()) + ([v for v in sd.values() if v.requires_grad] if stage == "fine" else [])
+    wnames = list(leaves.keys()) + ([k for k, v in sd.items() if v.requires_grad] if stage == "fine" else [])
+    g_ref = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
+
+    pc = pc.to(dev)
+    res = fd.render(cam.to(dev), pc, synthetic.PipelineParams(), torch.zeros(3, device=dev), stage=stage)
+    img = res["render"]
+    d = np.abs(img.detach().cpu().numpy() - o.color)
+    psnr = 10 * math.log10(1.0 / max(float((d ** 2).mean()), 1e-20))
+    print(f"[render {cfg} {stage}] max|dC|={d.max():.2e} mean={d.mean():.2e} psnr={psnr:.1f} dB, visible={(o.radii > 0).sum()}")
+    assert d.mean() < 5e-6 and psnr > 75.0
+    assert res["depth"].shape == (1, H, W) and res["radii"].shape == (n,) and res["visibility_filter"].dtype == torch.bool
+    (img * torch.tensor(dc, device=dev)).sum().backward()
+    torch.cuda.synchronize()
+    gp = dict(pc.named_parameters())
+    rep = {}
+    for k, b in zip(wnames, g_ref):
+        a = gp[k if k in gp else "_deformation." + k].grad
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) < 1e-12, k
+            continue
+        rep[k] = rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape))
+    worst = sorted(rep.items(), key=lambda kv: -kv[1])[:5]
+    print("   worst grad rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    for k, v in rep.items():
+        assert v < 1e-3, (k, v)
+    assert rel_l2(res["viewspace_points"].grad.cpu().numpy(), go["means2D"]) < 1e-3
