@@ -6,7 +6,7 @@ Sub-modules: rasterizer (drop-in for `diff_gaussian_rasterization`), deformation
 renderer (`render()` of gaussian_renderer/__init__.py:18), parallel (frame-parallel driver), synthetic (test scenes).
 The HIP library is loaded lazily on first use and there is no CPU fallback.
 """
-from . import _lib, deformation, rasterizer, renderer, sh, synthetic  # noqa: F401
+from . import _lib, deformation, parallel, rasterizer, renderer, sh, synthetic  # noqa: F401
 from .deformation import deform_network  # noqa: F401
 from .renderer import render  # noqa: F401
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401

@@ -55,6 +55,8 @@ SYMBOLS = {
     "fdgs_last_error": (c_char_p, []),
     "fdgs_abi_version": (c_int, []),
     "fdgs_device_arch": (c_int, [c_int, c_char_p, c_size_t]),
+    "fdgs_timing_enable": (c_int, [c_int]),
+    "fdgs_timing_report": (c_int, [c_char_p, c_size_t, c_int]),
     "fdgs_geom_bytes": (c_int, [c_int, POINTER(c_size_t)]),
     "fdgs_img_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "fdgs_binning_bytes": (c_int, [c_uint32, c_int, c_int, POINTER(c_size_t)]),

@@ -1,8 +1,39 @@
 // api.hip -- library-wide entry points of libfdgs: error string, version, device query, L1 statistics kernel.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace fdgs {
 thread_local char g_err[512] = {0};
+
+bool g_timing_on = false;
+namespace {
+struct TimingRec { const char* name; hipEvent_t e0, e1; };
+std::mutex g_tmu;
+std::vector<TimingRec> g_pool;   // event pairs, reused between reports
+size_t g_used = 0;
+std::map<std::string, std::pair<long, double>> g_totals;
+}  // namespace
+
+void* timing_begin(const char* name, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (g_used == g_pool.size()) {
+        TimingRec r{};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return nullptr;
+        g_pool.push_back(r);
+    }
+    TimingRec* r = &g_pool[g_used++];
+    r->name = name;
+    (void)hipEventRecord(r->e0, stream);
+    return (void*)(g_used);  // 1-based index (the vector may reallocate)
+}
+void timing_end(void* rec, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    (void)hipEventRecord(g_pool[(size_t)rec - 1].e1, stream);
+}
 
 // [sum |a-b|, sum (a-b)^2, n] with optional dL/da = sign(a-b)*scale (utils/loss_utils.py:20-21 of the reference)
 __global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, const float* __restrict__ a, const float* __restrict__ b,
@@ -31,6 +62,36 @@ using namespace fdgs;
 extern "C" const char* fdgs_last_error(void) { return g_err; }
 extern "C" int fdgs_abi_version(void) { return 1; }
 
+extern "C" int fdgs_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timing_on = on != 0;
+    return FDGS_OK;
+}
+
+// Synchronises the device, folds the recorded event pairs into per-kernel totals and prints "name count total_ms" lines.
+extern "C" int fdgs_timing_report(char* buf, size_t buflen, int reset) {
+    FDGS_REQUIRE(buf && buflen > 0, "bad arguments");
+    FDGS_HIP_CHECK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (size_t i = 0; i < g_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_pool[i].e0, g_pool[i].e1) == hipSuccess) {
+            auto& t = g_totals[g_pool[i].name];
+            t.first += 1; t.second += ms;
+        }
+    }
+    g_used = 0;
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto& kv : g_totals) {
+        int n = snprintf(buf + off, buflen - off, "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        if (n < 0 || (size_t)n >= buflen - off) break;
+        off += (size_t)n;
+    }
+    if (reset) g_totals.clear();
+    return FDGS_OK;
+}
+
 extern "C" int fdgs_device_arch(int dev, char* buf, size_t buflen) {
     FDGS_REQUIRE(buf && buflen > 0, "bad arguments");
     int n = 0;
@@ -48,7 +109,7 @@ extern "C" int fdgs_l1_stats(void* stream_, size_t n, const float* a, const floa
     hipStream_t stream = (hipStream_t)stream_;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(256), 0, stream, n, a, b, grad_scale, grad_out_opt, acc);
+    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(256), 0, stream, n, a, b, grad_scale, grad_out_opt, acc); }
     FDGS_LAUNCH_CHECK("l1_stats", 0, stream);
     return FDGS_OK;
 }

@@ -183,13 +183,13 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
         for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
             uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
             uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, hist, nblocks);
+            { FDGS_TIMED("radix_hist", stream); hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, hist, nblocks); }
             FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
-            hipLaunchKernelGGL((scan_kernel<false, false>), dim3(1), dim3(1024), 0, stream, hist, (const uint32_t*)nullptr, hist,
-                               (uint32_t)(RADIX * nblocks));
+            { FDGS_TIMED("radix_scan", stream); hipLaunchKernelGGL((scan_kernel<false, false>), dim3(1), dim3(1024), 0, stream, hist, (const uint32_t*)nullptr, hist,
+                               (uint32_t)(RADIX * nblocks)); }
             FDGS_LAUNCH_CHECK("radix_scan", debug, stream);
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist,
-                               nblocks);
+            { FDGS_TIMED("radix_scatter", stream); hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist,
+                               nblocks); }
             FDGS_LAUNCH_CHECK("radix_scatter", debug, stream);
             cur ^= 1;
         }
@@ -302,8 +302,8 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     if (in != 0) {  // keep the contract "sorted ids live in ids0" for any pass count
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(geom, gl.ids0), sorted_ids, (size_t)p->P * 4, hipMemcpyDeviceToDevice, stream));
     }
-    hipLaunchKernelGGL((scan_kernel<true, true>), dim3(1), dim3(1024), 0, stream, at<uint32_t>(geom, gl.tiles),
-                       at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P);
+    { FDGS_TIMED("scan_tiles", stream); hipLaunchKernelGGL((scan_kernel<true, true>), dim3(1), dim3(1024), 0, stream, at<uint32_t>(geom, gl.tiles),
+                       at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P); }
     {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { (void)hipEventDestroy(ev); return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }
@@ -326,9 +326,9 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     if (p->P == 0 || R == 0) return FDGS_OK;
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
-    hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
+    { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), il.gx,
-                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0));
+                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0)); }
     FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.tile1),
@@ -341,8 +341,8 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.gid1), (size_t)R * 4,
                                       hipMemcpyDeviceToDevice, stream));
     }
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 256)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
-                       at<uint2>(img, il.ranges));
+    { FDGS_TIMED("tile_ranges", stream); hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 256)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
+                       at<uint2>(img, il.ranges)); }
     FDGS_LAUNCH_CHECK("tile_ranges", p->debug, stream);
     return FDGS_OK;
 }

@@ -31,6 +31,18 @@ inline int fail(int code, const char* fmt, const char* a = "", const char* b = "
         if (!(cond)) return fdgs::fail(FDGS_E_INVALID, "%s", msg);    \
     } while (0)
 
+// ---- optional per-kernel HIP-event timing (bench.py's live roofline measurement; off by default) ----
+extern bool g_timing_on;
+void* timing_begin(const char* name, hipStream_t stream);
+void timing_end(void* rec, hipStream_t stream);
+struct KernelTimer {
+    void* rec;
+    hipStream_t s;
+    KernelTimer(const char* name, hipStream_t stream) : rec(g_timing_on ? timing_begin(name, stream) : nullptr), s(stream) {}
+    ~KernelTimer() { if (rec) timing_end(rec, s); }
+};
+#define FDGS_TIMED(name, stream) fdgs::KernelTimer fdgs_kt_##__LINE__(name, stream)
+
 constexpr int TILE = FDGS_TILE;
 constexpr int TILE_PIX = TILE * TILE;  // 256 threads = 4 wave64 per tile
 constexpr int WAVE = 64;

@@ -687,7 +687,10 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     hipStream_t stream = (hipStream_t)stream_;
     DeformDev d;
     d.p = *p; d.out = *out; d.F = p->C * p->L;
-    rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, cdiv(p->N, 128), d);
+    {
+        FDGS_TIMED("deform_fwd", stream);
+        rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, cdiv(p->N, 128), d);
+    }
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_fwd", 0, stream);
     return FDGS_OK;
@@ -731,7 +734,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     pa.out_scales = g->out_scales; pa.out_rot = g->out_rotations; pa.out_opacity = g->out_opacity; pa.rot_norm = g->rot_norm;
     pa.d_xyz = g->d_xyz; pa.d_scales = g->d_scales; pa.d_rot = g->d_rotations; pa.d_opacity = g->d_opacity;
     pa.d_shs_dc = g->d_shs_dc; pa.d_shs_rest = g->d_shs_rest; pa.G = s.G;
-    hipLaunchKernelGGL(deform_bwd_prep_kernel, dim3(cdiv((long long)Np, 256)), dim3(256), 0, stream, pa);
+    { FDGS_TIMED("deform_bwd_prep", stream); hipLaunchKernelGGL(deform_bwd_prep_kernel, dim3(cdiv((long long)Np, 256)), dim3(256), 0, stream, pa); }
     FDGS_LAUNCH_CHECK("deform_bwd_prep", 0, stream);
     if (nh == 0) return FDGS_OK;  // no head active: the deformation is the identity
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++)
@@ -744,7 +747,10 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         bd.d_w2[hd] = g->d_w2[hd]; bd.d_b2[hd] = g->d_b2[hd];
         bd.head_slot[hd] = p->head_on[hd] ? slot++ : 0;
     }
-    rc = dispatch_wf<BwdLauncher>(p->W, (int)F, stream, (int)(Np / 128), bd);
+    {
+        FDGS_TIMED("deform_bwd_data", stream);
+        rc = dispatch_wf<BwdLauncher>(p->W, (int)F, stream, (int)(Np / 128), bd);
+    }
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_bwd_data", 0, stream);
     // weight gradients: one job per active head (dW1, db1) + the trunk (dW0, db0)
@@ -769,8 +775,8 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     if (chunk < 64) chunk = 64;
     wa.chunk = chunk;
     const int kblocks = (int)((Np + chunk - 1) / chunk);
-    if (W == 128) hipLaunchKernelGGL((deform_wgrad_kernel<4>), dim3(kblocks, nj), dim3(256), 0, stream, wa);
-    else hipLaunchKernelGGL((deform_wgrad_kernel<2>), dim3(kblocks, nj), dim3(256), 0, stream, wa);
+    if (W == 128) { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<4>), dim3(kblocks, nj), dim3(256), 0, stream, wa); }
+    else { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<2>), dim3(kblocks, nj), dim3(256), 0, stream, wa); }
     FDGS_LAUNCH_CHECK("deform_wgrad", 0, stream);
     // plane + coordinate gradients
     bool any_plane = g->d_xyz != nullptr;
@@ -779,8 +785,8 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     for (int l = 0; l < p->L; l++)
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
-        if (p->C == 16) hipLaunchKernelGGL((deform_plane_grad_kernel<16>), dim3(cdiv(p->N, 8)), dim3(256), 0, stream, ga);
-        else hipLaunchKernelGGL((deform_plane_grad_kernel<32>), dim3(cdiv(p->N, 4)), dim3(256), 0, stream, ga);
+        if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<16>), dim3(cdiv(p->N, 8)), dim3(256), 0, stream, ga); }
+        else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<32>), dim3(cdiv(p->N, 4)), dim3(256), 0, stream, ga); }
         FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
     }
     return FDGS_OK;

@@ -204,7 +204,7 @@ extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, v
     a.recC = at<float4>(geom, gl.recC); a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles);
     a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
     a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a);
+    { FDGS_TIMED("preprocess_fwd", stream); hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
     return FDGS_OK;
 }
@@ -223,7 +223,7 @@ int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, 
     a.dL_dmeans2D = g->dL_dmeans2D; a.gacc = g->scratch_acc; a.dL_dopacity = g->dL_dopacity;
     a.dL_dcolors = g->dL_dcolors; a.dL_dmeans3D = g->dL_dmeans3D; a.dL_dsh = g->dL_dsh; a.dL_dscales = g->dL_dscales;
     a.dL_drot = g->dL_drotations; a.dL_dcov3D = g->dL_dcov3D;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a);
+    { FDGS_TIMED("preprocess_bwd", stream); hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_bwd", p->debug, stream);
     return FDGS_OK;
 }
@@ -234,7 +234,7 @@ extern "C" int fdgs_mark_visible(void* stream_, int P, const float* means3D, con
     FDGS_REQUIRE(P >= 0 && (P == 0 || (means3D && viewmatrix && present)), "bad arguments");
     if (P == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3(cdiv(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    { FDGS_TIMED("mark_visible", stream); hipLaunchKernelGGL(mark_visible_kernel, dim3(cdiv(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix, present); }
     FDGS_LAUNCH_CHECK("mark_visible", 0, stream);
     return FDGS_OK;
 }

@@ -247,7 +247,7 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
     a.out_color = out_color; a.out_depth = out_depth;
     const int ntiles = il.gx * il.gy;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+    { FDGS_TIMED("render_fwd", stream); hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("render_fwd", p->debug, stream);
     return FDGS_OK;
 }
@@ -285,7 +285,7 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
         a.gacc = g->scratch_acc;
         const int ntiles = il.gx * il.gy;
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+        { FDGS_TIMED("render_bwd", stream); hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a); }
         FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);
     }
     return fdgs_launch_preprocess_bwd(stream, p, geom, g);

@@ -287,7 +287,7 @@ class _DeformFunction(torch.autograd.Function):
             d_sha, d_shb = z(N, 1, 3), z(N, 15, 3)
             g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_shb.data_ptr()
         g.d_xyz, g.d_scales, g.d_rotations, g.d_opacity = ptr(d_xyz), ptr(d_sc), ptr(d_rot), ptr(d_op)
-        d_planes = [torch.zeros(s, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+        d_planes = [torch.empty(s, device=dev, dtype=torch.float32, memory_format=torch.channels_last).zero_()
                     for s in ctx.plane_shapes]
         for l in range(cfg["L"]):
             for k in range(6):

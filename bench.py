@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- train-step frames/s of the MI355X-native 4D-Gaussian render path (BASELINE.json metric).
+
+One step = one frame: render() forward (HexPlane + deformation MLP -> projection -> binning/sort -> alpha blending) and
+the full backward to every Gaussian parameter and every deformation parameter, for the L1-loss gradient against a
+fixed random target, at BASELINE config 4 shape (DyNeRF cook_spinach: 300k Gaussians, 1352x1014, dynerf deformation
+config, all five heads).  N GPUs = N independent frames per step (weak scaling) + one RCCL all-reduce of the loss
+statistics.  Synthetic scene: no datasets/checkpoints exist offline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12        # B/s spec (MI355X_MICROARCH.md); 6.29e12 measured copy
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, v_mfma_f32_32x32x2_f32
+
+WORKLOADS = {
+    # name: (N gaussians, W, H, deformation config)
+    "cfg4_dynerf_300k_1352x1014": (300_000, 1352, 1014, "dynerf_default"),
+    "cfg2_dnerf_100k_800x800": (100_000, 800, 800, "dnerf_bouncingballs"),
+    "cfg3_hypernerf_300k_536x960": (300_000, 536, 960, "hypernerf_default"),
+    "cfg5_stress_2M_2048x2048": (2_000_000, 2048, 2048, "dynerf_default"),
+    "tiny": (20_000, 400, 400, "dynerf_default"),
+}
+
+
+def mlp_flops_fwd(cfg):
+    F = cfg["kplanes_config"]["output_coordinate_dim"] * len(cfg["multires"])
+    W = cfg["net_width"]
+    ks = [k for k, off in zip((3, 3, 4, 1, 48), (cfg["no_dx"], cfg["no_ds"], cfg["no_dr"], cfg["no_do"], cfg["no_dshs"])) if not off]
+    return 2 * F * W + sum(2 * W * W + 2 * W * k for k in ks)
+
+
+def algorithmic_bytes(N, R, Px, G, d):
+    """SURVEY.md 8(d) per-stage algorithmic HBM bytes of one fwd+bwd frame."""
+    p = 6
+    return dict(deform_fwd=N * (236 + 44 + 192 * d) + G, deform_bwd=N * (236 + 44 + 192 * d) + N * 236 + 2 * G,
+                preprocess_fwd=N * (236 + 76), binning=N * 8 + R * 12 + R * 12 * 2 * p + R * 8,
+                render_fwd=R * 44 + Px * 24, render_bwd=R * 44 + Px * 20 + R * 36 * 2, preprocess_bwd=N * (36 + 76 + 236 + 236))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="cfg4_dynerf_300k_1352x1014", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    args = ap.parse_args()
+
+    fdgs = importlib.import_module("4dgaussians_amd")
+    par, syn = fdgs.parallel, fdgs.synthetic
+    rank, world, dev = par.init_from_env()
+    if dev.type != "cuda":
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    L = fdgs._lib.lib()
+    N, W, H, dcfg = WORKLOADS[args.workload]
+    pc = syn.SynthModel(N, dcfg, seed=6666, device=dev)
+    pipe = syn.PipelineParams()
+    bg = torch.zeros(3, device=dev)
+    cams = [c.to(dev) for c in syn.orbit_cameras(W, H, n=160)]
+    target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(6666)).to(dev)
+    params = [p for p in pc.parameters() if p.requires_grad]
+    acc = torch.zeros(3, device=dev)
+    dimg = torch.empty(3, H, W, device=dev)
+    st = fdgs._lib.stream_ptr
+    ptr = fdgs._lib.ptr
+    info = {}
+
+    def step(i):
+        cam = cams[par.frames_for_rank(len(cams), i, rank, world)]
+        for p_ in params:
+            p_.grad = None
+        res = fdgs.render(cam, pc, pipe, bg, stage="fine")
+        img = res["render"]
+        acc.zero_()
+        fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc)))
+        img.backward(dimg)
+        par.allreduce_loss_stats(acc)   # the only cross-GPU exchange of the path
+        info["radii"] = res["radii"]
+        return acc
+
+    for i in range(args.warmup):
+        step(i)
+    par.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    par.barrier(); torch.cuda.synchronize()
+    dt = par.max_over_ranks(time.perf_counter() - t0, dev)
+    l1, psnr = par.loss_from_stats(acc.clone())
+    fps = world * args.steps / dt
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate instrumented pass over the same steps)
+    kern = {}
+    L.fdgs_timing_enable(1)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    fdgs._lib.check(L.fdgs_timing_report(buf, len(buf), 1))
+    L.fdgs_timing_enable(0)
+    for line in buf.value.decode().strip().splitlines():
+        name, cnt, tot = line.split()
+        kern[name] = dict(launches_per_step=int(cnt) / args.steps, ms_per_step=float(tot) / args.steps,
+                          avg_ms=float(tot) / int(cnt))
+    # frame statistics for the byte model: one more forward to read num_rendered / visible count
+    with torch.no_grad():
+        cam = cams[par.frames_for_rank(len(cams), args.warmup, rank, world)]
+        out = fdgs.deformation.deform(pc._deformation, pc._xyz, pc._scaling, pc._rotation, pc._opacity,
+                                      shs_dc=pc._features_dc, shs_rest=pc._features_rest, time=cam.time, activate=True)
+        rs = fdgs.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+                                                cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+        _, radii, _, state = fdgs.rasterizer.rasterize_forward(rs, out[0], out[4], None, out[3], out[1], out[2], None)
+        R, V = int(state.num_rendered), int((radii > 0).sum())
+    cfg = syn.DEFORM_CONFIGS[dcfg]
+    G = sum(p_.numel() for n_, p_ in pc._deformation.named_parameters() if "grids" in n_) * 4
+    d_sh = 0 if cfg["no_dshs"] else 1
+    stage_bytes = algorithmic_bytes(N, R, W * H, G, d_sh)
+    B_frame = sum(stage_bytes.values())
+    flops_fwd = mlp_flops_fwd(cfg) * N
+    ms_step = dt / args.steps * 1e3
+    # dominant kernel and its roofline
+    dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    mfma_flops = {"deform_fwd": flops_fwd, "deform_bwd_data": 2 * flops_fwd, "deform_wgrad": flops_fwd}
+    hbm_bytes = {"render_bwd": stage_bytes["render_bwd"], "render_fwd": stage_bytes["render_fwd"],
+                 "preprocess_fwd": stage_bytes["preprocess_fwd"], "preprocess_bwd": stage_bytes["preprocess_bwd"],
+                 "deform_plane_grad": N * 12 + N * (cfg["kplanes_config"]["output_coordinate_dim"] * len(cfg["multires"])) * 4 + 2 * G,
+                 "radix_scatter": R * 16, "radix_hist": R * 4, "expand_pairs": R * 8 + N * 16, "deform_bwd_prep": N * (59 * 8 + 256)}
+    roof = None
+    if dom:
+        t_dom = kern[dom]["avg_ms"] * 1e-3
+        lps = max(kern[dom]["launches_per_step"], 1e-9)
+        if dom in mfma_flops:
+            a = mfma_flops[dom] / lps / t_dom
+            roof = dict(kernel=dom, bound="mfma", achieved=a / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
+                        frac=a / MFMA_F32_PEAK, traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps)
+        else:
+            a = hbm_bytes.get(dom, 0) / lps / t_dom
+            roof = dict(kernel=dom, bound="hbm", achieved=a / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=a / HBM_PEAK,
+                        traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(fdgs, syn, pc, cams[args.warmup % len(cams)], target, dcfg, args.cpu_frames)
+
+    if rank == 0:
+        out = {
+            "metric": "train-step frames/sec (fwd+bwd raster+deform)", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
+                       "frames_per_step": world, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
+            "roofline": roof, "cpu_baseline": cpu,
+            "frame_hbm": {"algorithmic_bytes": B_frame, "achieved_GBps": B_frame / (dt / args.steps / 1) / 1e9 if world == 1 else None,
+                          "frac_of_8TBps": (B_frame / (dt / args.steps)) / HBM_PEAK if world == 1 else None,
+                          "note": "working set < 256 MiB Infinity Cache at this size: the HBM fraction is structurally small"},
+            "mlp": {"fwd_bwd_flops": 3 * flops_fwd,
+                    "achieved_TFLOPs_in_mfma_kernels": (3 * flops_fwd / (sum(kern[k]["ms_per_step"] for k in mfma_flops if k in kern) * 1e-3) / 1e12)
+                    if kern else None, "peak_TFLOPs": MFMA_F32_PEAK / 1e12},
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "gpu_kernel_ms_per_step": round(sum(v["ms_per_step"] for v in kern.values()), 4),
+            "loss": {"l1": float(l1), "psnr": float(psnr)},
+        }
+        print(json.dumps(out))
+
+
+def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
+    """The same frame on the host cores: oracle deformation (torch CPU) -> oracle rasterizer (C, OpenMP), fwd + bwd.
+    kind = "port": the rasterizer restatement is ours (the reference has no CPU rasterizer); the deformation oracle is
+    pinned to the reference's modules (tests/test_oracle_deform.py)."""
+    import numpy as np
+    from oracle import deform_oracle as DO
+    from oracle.raster_oracle import RasterOracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().contiguous().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in pc._deformation.state_dict().items()}
+    leaves = {k: getattr(pc, k).detach().cpu().clone().requires_grad_(True)
+              for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    flags = syn.deform_args(dcfg)
+    cam = cam.to("cpu")
+    tgt = target.cpu().numpy()
+    n = leaves["_xyz"].shape[0]
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
+        outs = DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
+                                 torch.full((n, 1), cam.time), activate=True)
+        f = lambda x: np.ascontiguousarray(x.detach().numpy())
+        o = RasterOracle(means3D=f(outs[0]), scales=f(outs[1]), rotations=f(outs[2]), opacities=f(outs[3]), shs=f(outs[4]),
+                         viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
+                         bg=np.zeros(3, np.float32), image_height=cam.image_height, image_width=cam.image_width,
+                         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+        dc = (np.sign(o.color - tgt) / o.color.size).astype(np.float32)
+        g = o.backward(dc)
+        gouts = [torch.tensor(g["means3D"]), torch.tensor(g["scales"]), torch.tensor(g["rotations"]),
+                 torch.tensor(g["opacities"]).reshape(outs[3].shape), torch.tensor(g["shs"]).reshape(outs[4].shape)]
+        torch.autograd.grad(list(outs), list(leaves.values()) + [v for v in sd.values() if v.requires_grad], grad_outputs=gouts,
+                            allow_unused=True)
+        o.close()
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s of CPU time on {cores} threads; "
+                      "deformation = oracle pinned to the reference modules, rasterizer = our C restatement (OpenMP)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,10 @@ extern "C" {
 const char* fdgs_last_error(void);
 /* ABI version of this header; bump on any signature change. */
 int fdgs_abi_version(void);
+/* Optional per-kernel timing with HIP events on the launch stream (off by default; used by bench.py for the live
+ * roofline measurement).  fdgs_timing_report synchronises the device and writes "kernel_name count total_ms" lines. */
+int fdgs_timing_enable(int on);
+int fdgs_timing_report(char* buf, size_t buflen, int reset);
 /* Name (gcnArchName) of device `dev` into buf; FDGS_E_NOGPU if none. */
 int fdgs_device_arch(int dev, char* buf, size_t buflen);
 

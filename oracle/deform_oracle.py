@@ -91,6 +91,34 @@ def deform_forward(sd, flags, xyz, scales, rotations, opacity, shs, t, activate=
     return pts, sc, rot, op, sh
 
 
+def discontinuity_margin(sd, flags, xyz, t):
+    """Per Gaussian: distance to the nearest derivative discontinuity of the deformation field = min over
+    (|pre-activation| of every ReLU input, distance of every spatial plane coordinate to a texel boundary in pixels).
+    Tests use it to pick inputs on which float rounding cannot flip a ReLU or a bilinear cell."""
+    with torch.no_grad():
+        n_levels = count_levels(sd)
+        feat = hexplane_features(sd, xyz, t, n_levels)
+        hidden = F.linear(feat, sd["deformation_net.feature_out.0.weight"], sd["deformation_net.feature_out.0.bias"])
+        margin = hidden.abs().min(dim=1).values
+        for (name, flag, k) in HEADS:
+            if getattr(flags, flag):
+                continue
+            h = F.linear(torch.relu(hidden), sd[f"deformation_net.{name}.1.weight"], sd[f"deformation_net.{name}.1.bias"])
+            margin = torch.minimum(margin, h.abs().min(dim=1).values)
+        aabb = sd["deformation_net.grid.aabb"]
+        pts = (xyz - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0
+        for lvl in range(n_levels):
+            for axis, plane in ((0, 0), (1, 0), (2, 1)):  # plane (0,1) carries x (width) and y (height); (0,2) carries z
+                pl = sd[f"deformation_net.grid.grids.{lvl}.{plane}"]
+                size = pl.shape[3] if axis == 0 else pl.shape[2]
+                p = ((pts[:, axis] + 1.0) / 2.0) * (size - 1)
+                frac = (p - torch.floor(p)).clamp(0, 1)
+                dist = torch.minimum(frac, 1 - frac)
+                dist = torch.where((p < 0) | (p > size - 1), torch.minimum((p - 0).abs(), (p - (size - 1)).abs()), dist)
+                margin = torch.minimum(margin, dist * 0.1)
+    return margin
+
+
 def import_reference_deform_network():
     """import the reference's own deform_network on CPU (only where /root/reference exists)."""
     import sys

@@ -19,7 +19,7 @@ def _fdgs():
     return importlib.import_module("4dgaussians_amd")
 
 
-def _net_and_inputs(cfg, n, seed, dev, overrides=None):
+def _net_and_inputs(cfg, n, seed, dev, overrides=None, safe=True):
     fd = _fdgs()
     torch.manual_seed(seed)
     args = synthetic.deform_args(cfg, **(overrides or {}))
@@ -29,13 +29,21 @@ def _net_and_inputs(cfg, n, seed, dev, overrides=None):
         for name, p in net.named_parameters():
             if "grids" in name:
                 p.add_(0.1 * torch.randn(p.shape, generator=gen))
-    g = synthetic.make_gaussians(n, seed=seed)
+    m = 2 * n + 64 if safe else n
+    g = synthetic.make_gaussians(m, seed=seed)
     xyz = g["xyz"] * 1.05  # a few points outside the aabb: border clamp + zero coordinate gradient
     net.deformation_net.set_aabb([1.3, 1.25, 1.2], [-1.3, -1.2, -1.25])
     shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
-    t = torch.rand(n, 1, generator=gen)
-    t[: min(4, n)] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])[: min(4, n)]
+    t = torch.rand(m, 1, generator=gen)
+    t[:4] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])
     ins = [xyz, g["scaling"], g["rotation"], g["opacity"], shs, t]
+    if safe:
+        # keep Gaussians that sit at least 1e-4 away from every ReLU kink / texel boundary: there float32 rounding
+        # (GPU fmaf chain vs CPU sgemm) cannot flip a derivative, so gradients can be compared tightly
+        margin = DO.discontinuity_margin(net.state_dict(), args, xyz, t)
+        keep = torch.nonzero(margin > 1e-4).squeeze(1)[:n]
+        assert keep.numel() == n, f"only {keep.numel()} safe Gaussians"
+        ins = [x[keep].contiguous() for x in ins]
     return args, net, ins
 
 
@@ -80,8 +88,41 @@ def test_deform_forward_backward_parity(cfg, n, activate):
         report[k] = rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape))
     worst = sorted(report.items(), key=lambda kv: -kv[1])[:4]
     print(f"[{cfg} n={n} act={activate}] worst grad rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    for k, a, b in zip(list(names) + pnames, g_gpu, g_ref):
+        if b is not None and report.get(k, 0) >= 1e-4:  # diagnostics: is the error confined to a few rows?
+            A, B = a.cpu().numpy().reshape(a.shape[0], -1), b.numpy().reshape(a.shape[0], -1)
+            rowerr = np.linalg.norm(A - B, axis=1) / (np.linalg.norm(B) / math.sqrt(A.shape[0]) + 1e-30)
+            bad = np.argsort(-rowerr)[:5]
+            print(f"   {k}: rows with largest error {bad.tolist()} -> {np.round(rowerr[bad], 4).tolist()}")
     for k, v in report.items():
-        assert v < 1e-3, (k, v)
+        assert v < 1e-4, (k, v)
+
+
+@pytest.mark.parametrize("cfg,n", [("dynerf_default", 3000)])
+def test_deform_unfiltered_inputs_loose(cfg, n):
+    """Unfiltered random inputs: a handful of the ~2M ReLU inputs lie within float rounding of 0 and flip between the
+    GPU's fmaf chain and the CPU's sgemm; each flip perturbs a single row of a weight gradient.  The comparison is
+    therefore loose here (and tight on inputs away from the kinks above)."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs(cfg, n, 9, dev, safe=False)
+    sd = {k: v.detach().clone().contiguous().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in net.state_dict().items()}
+    cpu_in = [x.clone().requires_grad_(i < 5) for i, x in enumerate(ins)]
+    ref = DO.deform_forward(sd, args, *cpu_in, activate=True)
+    net = net.to(dev)
+    gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
+    out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=True)
+    for a, b in zip(out, ref):
+        assert rel_l2(a.detach().cpu().numpy(), b.detach().numpy().reshape(a.shape)) < 2e-5
+    ws = [torch.randn(b.shape, generator=torch.Generator().manual_seed(1)) for b in ref]
+    pn = [k for k in sd if sd[k].requires_grad]
+    g_ref = torch.autograd.grad(sum((a * w).sum() for a, w in zip(ref, ws)), cpu_in[:5] + [sd[k] for k in pn], allow_unused=True)
+    g_gpu = torch.autograd.grad(sum((a * w.to(dev).reshape(a.shape)).sum() for a, w in zip(out, ws)),
+                                gpu_in[:5] + [dict(net.named_parameters())[k] for k in pn], allow_unused=True)
+    for a, b in zip(g_gpu, g_ref):
+        if b is not None:
+            assert rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape)) < 2e-2
 
 
 def test_module_api_matches_reference_signature_and_scalar_time():
