@@ -19,49 +19,116 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// ---------------------------------------------------------------- single-workgroup scan (1024 threads x 4 items)
-// in-place capable; GATHER: value i = src[idx[i]]
-template <bool GATHER, bool INCLUSIVE>
-__global__ void __launch_bounds__(1024) scan_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
-                                                    uint32_t* __restrict__ dst, uint32_t n) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (t == 0) carry_s = 0;
+// ---------------------------------------------------------------- scans (all multi-workgroup)
+// block-wide exclusive prefix of one value per thread (256 threads); *total = sum over the block
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wtmp /*[4] LDS*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += u;
+    }
+    if (lane == 63) wtmp[w] = inc;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
+    const uint32_t s0 = wtmp[0], s1 = wtmp[1], s2 = wtmp[2], s3 = wtmp[3];
+    const uint32_t wp = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+    *total = s0 + s1 + s2 + s3;
+    __syncthreads();  // wtmp may be reused by the caller's next round
+    return wp + inc - v;
+}
+
+// Radix offsets, step 1: workgroup d scans row d of hist[digit][block] (exclusive, in place) and writes the digit
+// total.  256 workgroups instead of one: the R-pair sort of a 1352x1014 frame has 256 x 1556 counters per pass.
+__global__ void __launch_bounds__(256) radix_digit_scan_kernel(uint32_t* __restrict__ hist, int nblocks,
+                                                               uint32_t* __restrict__ dtot) {
+    __shared__ uint32_t wtmp[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    const int t = threadIdx.x;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 1024) {
         uint32_t v[4];
-        const uint32_t i0 = base + t * 4;
+        const int i0 = base + t * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < nblocks) ? row[i0 + k] : 0u;
+        uint32_t tot;
+        uint32_t run = carry + block_excl_scan_256(v[0] + v[1] + v[2] + v[3], wtmp, &tot);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t i = i0 + k;
-            v[k] = 0;
-            if (i < n) v[k] = GATHER ? src[idx[i]] : src[i];
-        }
-        uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-        uint32_t inc = tsum;  // wave inclusive scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(inc, o, 64);
-            if (lane >= (uint32_t)o) inc += u;
-        }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t wprefix = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) wprefix += (k < (int)w) ? wsum[k] : 0u;
-        const uint32_t carry = carry_s;
-        uint32_t run = carry + wprefix + inc - tsum;  // exclusive prefix of this thread's first item
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t i = i0 + k;
-            uint32_t excl = run;
+            if (i0 + k < nblocks) row[i0 + k] = run;
             run += v[k];
-            if (i < n) dst[i] = INCLUSIVE ? run : excl;
         }
-        __syncthreads();
-        if (t == 1023) carry_s = run;
-        __syncthreads();
+        carry += tot;
+    }
+    if (t == 0) dtot[blockIdx.x] = carry;
+}
+
+// Two-level scan of n values (GATHER: value i = src[idx[i]]): (1) every workgroup scans its 4096-value chunk
+// (inclusive) and publishes the chunk total, (2) every workgroup adds the totals of the chunks before it.
+constexpr int SCAN_CHUNK = 4096;
+template <bool GATHER>
+__global__ void __launch_bounds__(256) scan_chunk_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                                         uint32_t* __restrict__ dst, uint32_t n, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t wtmp[4];
+    const uint32_t i0 = blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+    uint32_t v[16];
+    if (i0 + 16 <= n) {
+        if (GATHER) {
+            uint32_t id[16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 q = reinterpret_cast<const uint4*>(idx + i0)[k];
+                id[4 * k] = q.x; id[4 * k + 1] = q.y; id[4 * k + 2] = q.z; id[4 * k + 3] = q.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = src[id[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 q = reinterpret_cast<const uint4*>(src + i0)[k];
+                v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = (i0 + k < n) ? (GATHER ? src[idx[i0 + k]] : src[i0 + k]) : 0u;
+    }
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { tsum += v[k]; v[k] = tsum; }   // thread-local inclusive
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan_256(tsum, wtmp, &tot);
+    if (i0 + 16 <= n) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            reinterpret_cast<uint4*>(dst + i0)[k] = make_uint4(v[4 * k] + excl, v[4 * k + 1] + excl, v[4 * k + 2] + excl, v[4 * k + 3] + excl);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (i0 + k < n) dst[i0 + k] = v[k] + excl;
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) scan_add_kernel(uint32_t* __restrict__ dst, uint32_t n, const uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t wtmp[4];
+    const uint32_t b = blockIdx.x + 1;  // chunk 0 needs nothing added
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < b; j += 256) part += bsum[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) wtmp[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const uint32_t add = wtmp[0] + wtmp[1] + wtmp[2] + wtmp[3];
+    const uint32_t i0 = b * SCAN_CHUNK + threadIdx.x * 16;
+    if (i0 + 16 <= n) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint4 q = reinterpret_cast<uint4*>(dst + i0)[k];
+            q.x += add; q.y += add; q.z += add; q.w += add;
+            reinterpret_cast<uint4*>(dst + i0)[k] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (i0 + k < n) dst[i0 + k] += add;
     }
 }
 
@@ -86,13 +153,15 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
                                                                      uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                                     const uint32_t* __restrict__ hist, int nblocks) {
+                                                                     const uint32_t* __restrict__ hist, int nblocks,
+                                                                     const uint32_t* __restrict__ dtot) {
     __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counters
     __shared__ uint32_t lbase[RADIX];     // start of digit d inside the block-local regrouped array
     __shared__ uint32_t gbase[RADIX];     // global start of (digit d, this block)
     __shared__ uint32_t skey[SORT_CHUNK];
     __shared__ uint32_t sval[SORT_CHUNK];
     __shared__ uint32_t wtmp[4];
+    __shared__ uint32_t wtmp2[4];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll
     for (int k = 0; k < 4; k++) wcnt[k][t] = 0;
@@ -133,19 +202,22 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
         const uint32_t tot = c0 + c1 + c2 + c3;
         wcnt[0][t] = 0; wcnt[1][t] = c0; wcnt[2][t] = c0 + c1; wcnt[3][t] = c0 + c1 + c2;
-        uint32_t inc = tot;
+        // two 256-wide exclusive scans at once: the block-local digit counts and the global digit totals
+        const uint32_t dt = dtot[t];
+        uint32_t inc = tot, dinc = dt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(inc, o, 64);
-            if (lane >= (uint32_t)o) inc += u;
+            uint32_t u = __shfl_up(inc, o, 64), du = __shfl_up(dinc, o, 64);
+            if (lane >= (uint32_t)o) { inc += u; dinc += du; }
         }
-        if (lane == 63) wtmp[w] = inc;
+        if (lane == 63) { wtmp[w] = inc; wtmp2[w] = dinc; }
         __syncthreads();
-        uint32_t wp = 0;
+        uint32_t wp = 0, dwp = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) wp += (k < (int)w) ? wtmp[k] : 0u;
+        for (int k = 0; k < 4; k++) { wp += (k < (int)w) ? wtmp[k] : 0u; dwp += (k < (int)w) ? wtmp2[k] : 0u; }
         lbase[t] = wp + inc - tot;
-        gbase[t] = hist[(size_t)t * nblocks + blockIdx.x];
+        // global start of (digit t, this block) = start of digit t + keys of digit t in earlier blocks
+        gbase[t] = (dwp + dinc - dt) + hist[(size_t)t * nblocks + blockIdx.x];
     }
     __syncthreads();
 #pragma unroll
@@ -185,11 +257,11 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
             uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
             { FDGS_TIMED("radix_hist", stream); hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, hist, nblocks); }
             FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
-            { FDGS_TIMED("radix_scan", stream); hipLaunchKernelGGL((scan_kernel<false, false>), dim3(1), dim3(1024), 0, stream, hist, (const uint32_t*)nullptr, hist,
-                               (uint32_t)(RADIX * nblocks)); }
+            uint32_t* dtot = hist + (size_t)RADIX * nblocks;  // 256 digit totals live in the slack behind the counters
+            { FDGS_TIMED("radix_scan", stream); hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RADIX), dim3(256), 0, stream, hist, nblocks, dtot); }
             FDGS_LAUNCH_CHECK("radix_scan", debug, stream);
             { FDGS_TIMED("radix_scatter", stream); hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist,
-                               nblocks); }
+                               nblocks, dtot); }
             FDGS_LAUNCH_CHECK("radix_scatter", debug, stream);
             cur ^= 1;
         }
@@ -302,8 +374,16 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     if (in != 0) {  // keep the contract "sorted ids live in ids0" for any pass count
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(geom, gl.ids0), sorted_ids, (size_t)p->P * 4, hipMemcpyDeviceToDevice, stream));
     }
-    { FDGS_TIMED("scan_tiles", stream); hipLaunchKernelGGL((scan_kernel<true, true>), dim3(1), dim3(1024), 0, stream, at<uint32_t>(geom, gl.tiles),
-                       at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P); }
+    {
+        // point_offsets = inclusive scan of tiles_touched in depth order; chunk totals reuse the (now idle) sort counters
+        FDGS_TIMED("scan_tiles", stream);
+        const int nchunks = cdiv(p->P, SCAN_CHUNK);
+        uint32_t* bsum = at<uint32_t>(geom, gl.hist);
+        hipLaunchKernelGGL((scan_chunk_kernel<true>), dim3(nchunks), dim3(256), 0, stream, at<uint32_t>(geom, gl.tiles),
+                           at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P, bsum);
+        if (nchunks > 1)
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nchunks - 1), dim3(256), 0, stream, at<uint32_t>(geom, gl.offsets), (uint32_t)p->P, bsum);
+    }
     {
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { (void)hipEventDestroy(ev); return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }

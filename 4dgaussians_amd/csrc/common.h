@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/fdgs.h"
@@ -46,6 +47,12 @@ struct KernelTimer {
 constexpr int TILE = FDGS_TILE;
 constexpr int TILE_PIX = TILE * TILE;  // 256 threads = 4 wave64 per tile
 constexpr int WAVE = 64;
+
+// integer tuning knob from the environment (development/diagnostics only; the defaults are the tuned values)
+inline int tunable(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

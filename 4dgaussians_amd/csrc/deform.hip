@@ -117,55 +117,167 @@ __device__ __forceinline__ void gather_features(const fdgs_deform_params& p, con
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA layers
-// out[ot] = bias + W[ot*32.., :] * in     (W row-major [out_dim][in_dim], in_dim = 8*KCH, rows >= out_dim read as 0)
-template <int KCH, int OT>
-__device__ __forceinline__ void dense(const float* __restrict__ Wm, const float* __restrict__ bias, int in_dim, int out_dim,
-                                      const f32x16* in, f32x16* out, int g, int h) {
-#pragma unroll
-    for (int ot = 0; ot < OT; ot++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = frow(ot, r, h);
-            out[ot][r] = row < out_dim ? bias[row] : 0.f;
-        }
+// Register layouts.  rho(r,h) = row of the 32x32 MFMA C/D tile that register r holds in lane half h.
+//   * "chunk" layout (HexPlane features, F = 8*FCH): tile j/4, registers 4(j%4)..+3 of lane (g,h) hold features
+//     8j+4h..+3 of Gaussian g  (== feature 32*tile + rho(r,h));
+//   * "interleaved" layout (hidden activations, T = W/32 tiles): tile t, register r of lane (g,h) holds feature
+//     T*rho(r,h) + t.  With it BOTH products read the torch-layout weights with one 16-byte load per lane:
+//       Y = W X   : A-lane (row, h) needs W[row][T*rho(r,h) + t], t = 0..T-1  -> one vector load per r feeds T MFMAs;
+//       dX = W^T dY: A-lane (i, h) needs W[f][T*i + xt],       xt = 0..T-1 -> one vector load per k-step feeds T MFMAs
+//     (the transposed product with the naive 32t+row layout needs T separate dword loads per k-step).
+// Every A operand is software-prefetched PD steps ahead (the compiler serialises load -> wait -> 4 MFMA otherwise:
+// round-1 profile, 52 % / 31 % MFMA utilisation in D1 / D2).
+__device__ __forceinline__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int VW>
+struct AVec { float v[VW]; };
+template <int VW>
+__device__ __forceinline__ AVec<VW> ldv(const float* __restrict__ p) {
+    AVec<VW> a;
+    if constexpr (VW == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        a.v[0] = q.x; a.v[1] = q.y; a.v[2] = q.z; a.v[3] = q.w;
+    } else if constexpr (VW == 2) {
+        const float2 q = *reinterpret_cast<const float2*>(p);
+        a.v[0] = q.x; a.v[1] = q.y;
+    } else {
+        a.v[0] = *p;
     }
-#pragma unroll
-    for (int j = 0; j < KCH; j++) {
-        float4 a4[OT];
-#pragma unroll
-        for (int ot = 0; ot < OT; ot++) {
-            const int row = ot * 32 + g;
-            a4[ot] = row < out_dim ? *reinterpret_cast<const float4*>(Wm + (size_t)row * in_dim + 8 * j + 4 * h)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int ot = 0; ot < OT; ot++) {
-            out[ot] = mfma32(a4[ot].x, in[j / 4][4 * (j % 4) + 0], out[ot]);
-            out[ot] = mfma32(a4[ot].y, in[j / 4][4 * (j % 4) + 1], out[ot]);
-            out[ot] = mfma32(a4[ot].z, in[j / 4][4 * (j % 4) + 2], out[ot]);
-            out[ot] = mfma32(a4[ot].w, in[j / 4][4 * (j % 4) + 3], out[ot]);
-        }
-    }
+    return a;
 }
 
-// dX[xt] += W^T dY : dX row (xt*32+g) valid below in_valid; W row-major [32*YT][ld]
-template <int YT, int XT>
-__device__ __forceinline__ void dense_bwd_data(const float* __restrict__ Wm, int ld, int in_valid, const f32x16* dY, f32x16* dX,
-                                               int g, int h) {
+// Y[ot] = bias + W X, X in interleaved layout (KT tiles, K = 32*KT), W row-major [out_dim][ld].
+// Output rows: ROW_IL ? interleaved (row = OT*i + ot) : standard (row = 32*ot + i), rows >= out_dim are duplicates
+// of the last valid row (never read back).  Usage: setup(); preload(); ...; run().
+template <int KT, int OT, bool ROW_IL, int PD, bool CLAMP = true>
+struct DenseIL {
+    const float* rp[OT];
+    AVec<KT> buf[PD][OT];
+    __device__ __forceinline__ void setup(const float* __restrict__ Wm, int ld, int out_dim, int g, int h) {
 #pragma unroll
-    for (int it = 0; it < YT; it++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int f = frow(it, r, h);
-#pragma unroll
-            for (int xt = 0; xt < XT; xt++) {
-                const int col = xt * 32 + g;
-                const float a = col < in_valid ? Wm[(size_t)f * ld + col] : 0.f;
-                dX[xt] = mfma32(a, dY[it][r], dX[xt]);
-            }
+        for (int ot = 0; ot < OT; ot++) {
+            int row = ROW_IL ? OT * g + ot : 32 * ot + g;
+            if (CLAMP) row = row < out_dim ? row : out_dim - 1;
+            rp[ot] = Wm + (size_t)row * ld + KT * 4 * h;
         }
     }
-}
+    __device__ __forceinline__ void fetch(int s, AVec<KT>* dst) const {
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) dst[ot] = ldv<KT>(rp[ot] + KT * rho(s, 0));
+    }
+    __device__ __forceinline__ void preload() {
+#pragma unroll
+        for (int s = 0; s < PD; s++) fetch(s, buf[s]);
+    }
+    __device__ __forceinline__ void run(const float* __restrict__ bias, int out_dim, const f32x16* X, f32x16* Y, int h) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+                int row = ROW_IL ? OT * rho(r, h) + ot : 32 * ot + rho(r, h);
+                if (CLAMP) row = row < out_dim ? row : out_dim - 1;
+                Y[ot][r] = bias[row];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            AVec<KT> cur[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) cur[ot] = buf[s % PD][ot];
+            if (s + PD < 16) fetch(s + PD, buf[s % PD]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD steps ahead (the scheduler sinks it to its use otherwise)
+#pragma unroll
+            for (int t = 0; t < KT; t++)
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(cur[ot].v[t], X[t][s], Y[ot]);
+        }
+    }
+};
+
+// hid[ot] = b0 + W0 feat: feat in chunk layout (FCH chunks of 8 features), output rows interleaved (row = OT*i + ot)
+template <int FCH, int OT, int PD>
+struct DenseTrunk {
+    const float* rp[OT];
+    float4 buf[PD][OT];
+    __device__ __forceinline__ void setup(const float* __restrict__ Wm, int ld, int g, int h) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) rp[ot] = Wm + (size_t)(OT * g + ot) * ld + 4 * h;
+    }
+    __device__ __forceinline__ void fetch(int j, float4* dst) const {
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) dst[ot] = *reinterpret_cast<const float4*>(rp[ot] + 8 * j);
+    }
+    __device__ __forceinline__ void preload() {
+#pragma unroll
+        for (int s = 0; s < PD; s++) if (s < FCH) fetch(s, buf[s]);
+    }
+    __device__ __forceinline__ void run(const float* __restrict__ bias, const f32x16* feat, f32x16* Y, int h) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) Y[ot][r] = bias[OT * rho(r, h) + ot];
+#pragma unroll
+        for (int j = 0; j < FCH; j++) {
+            float4 cur[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) cur[ot] = buf[j % PD][ot];
+            if (j + PD < FCH) fetch(j + PD, buf[j % PD]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(cur[ot].x, feat[j / 4][4 * (j % 4) + 0], Y[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(cur[ot].y, feat[j / 4][4 * (j % 4) + 1], Y[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(cur[ot].z, feat[j / 4][4 * (j % 4) + 2], Y[ot]);
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(cur[ot].w, feat[j / 4][4 * (j % 4) + 3], Y[ot]);
+        }
+    }
+};
+
+// dX[xt] += W^T dY: dY interleaved (YT tiles, feature f = YT*rho(r,h) + t), W row-major [32*YT][ld].
+// COL_IL: dX interleaved with XT tiles (column XT*i + xt, one vector load per k-step);
+// else:   dX in tile layout (column 32*xt + i, clamped to in_valid-1; rows beyond are never read back).
+template <int YT, int XT, bool COL_IL, int PD>
+struct DenseT {
+    static constexpr int VW = COL_IL ? XT : 1;
+    static constexpr int NL = COL_IL ? 1 : XT;   // loads per k-step
+    const float* cp[NL];
+    int ld;
+    AVec<VW> buf[PD][NL];
+    __device__ __forceinline__ void setup(const float* __restrict__ Wm, int ld_, int in_valid, int g, int h) {
+        ld = ld_;
+#pragma unroll
+        for (int x = 0; x < NL; x++) {
+            int col = COL_IL ? XT * g : 32 * x + g;
+            col = col < in_valid ? col : in_valid - 1;
+            cp[x] = Wm + (size_t)(YT * 4 * h) * ld_ + col;
+        }
+    }
+    // k-step s = (r, t): r = s / YT, t = s % YT  ->  weight row YT*rho(r,0) + t (+ YT*4*h folded into cp)
+    __device__ __forceinline__ void fetch(int s, AVec<VW>* dst) const {
+        const int r = s / YT, t = s % YT;
+#pragma unroll
+        for (int x = 0; x < NL; x++) dst[x] = ldv<VW>(cp[x] + (size_t)(YT * rho(r, 0) + t) * ld);
+    }
+    __device__ __forceinline__ void preload() {
+#pragma unroll
+        for (int s = 0; s < PD; s++) fetch(s, buf[s]);
+    }
+    __device__ __forceinline__ void run(const f32x16* dY, f32x16* dX) {
+#pragma unroll
+        for (int s = 0; s < 16 * YT; s++) {
+            AVec<VW> cur[NL];
+#pragma unroll
+            for (int x = 0; x < NL; x++) cur[x] = buf[s % PD][x];
+            if (s + PD < 16 * YT) fetch(s + PD, buf[s % PD]);
+            __builtin_amdgcn_sched_barrier(0);
+            const float b = dY[s % YT][s / YT];
+#pragma unroll
+            for (int xt = 0; xt < XT; xt++) dX[xt] = mfma32(COL_IL ? cur[0].v[xt] : cur[xt].v[0], b, dX[xt]);
+        }
+    }
+};
 
 template <int T>
 __device__ __forceinline__ void relu_inplace(f32x16* x) {
@@ -175,11 +287,30 @@ __device__ __forceinline__ void relu_inplace(f32x16* x) {
         for (int r = 0; r < 16; r++) x[t][r] = fmaxf(x[t][r], 0.f);
 }
 
+// interleaved activations -> row-major [n][W] global rows: register r of the T tiles = T consecutive features
+template <int T>
+__device__ __forceinline__ void store_il(float* __restrict__ rowp, const f32x16* x, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if constexpr (T == 4) *reinterpret_cast<float4*>(rowp + 4 * rho(r, h)) = make_float4(x[0][r], x[1][r], x[2][r], x[3][r]);
+        else *reinterpret_cast<float2*>(rowp + 2 * rho(r, h)) = make_float2(x[0][r], x[1][r]);
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+__device__ __forceinline__ int next_head(const int* head_on, int hd) {
+    hd++;
+    while (hd < FDGS_NUM_HEADS && !head_on[hd]) hd++;
+    return hd;
+}
+
 // ------------------------------------------------------------------------------------------------ D1 forward
+template <int WT>
+struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
+
 template <int WT, int FCH>
-__global__ void __launch_bounds__(256, 2) deform_fwd_kernel(DeformDev d) {
+__global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     const fdgs_deform_params& p = d.p;
     constexpr int FT = (FCH + 3) / 4;
     const int lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
@@ -187,6 +318,12 @@ __global__ void __launch_bounds__(256, 2) deform_fwd_kernel(DeformDev d) {
     const bool live = n_raw < p.N;
     const int n = live ? n_raw : p.N - 1;
     const int W = WT * 32;
+    DenseTrunk<FCH, WT, 2> T0;
+    T0.setup(p.w0, d.F, g, h);
+    T0.preload();
+    int hd = next_head(p.head_on, -1);
+    DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
+    if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
     load_query(p, n, q, xyz);
     f32x16 feat[FT];
@@ -194,20 +331,64 @@ __global__ void __launch_bounds__(256, 2) deform_fwd_kernel(DeformDev d) {
     for (int t = 0; t < FT; t++) feat[t] = zero16();
     gather_features<FCH>(p, q, h, feat);
     f32x16 hid[WT];
-    dense<FCH, WT>(p.w0, p.b0, d.F, W, feat, hid, g, h);
+    T0.run(p.b0, feat, hid, h);
     relu_inplace<WT>(hid);  // every consumer of the trunk output starts with ReLU (scene/deformation.py:61-65)
 
     const bool writer = live && h == 0;
-    for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
-        const int k = head_k(hd);
-        f32x16 o0 = zero16(), o1 = zero16();
-        if (p.head_on[hd]) {
-            f32x16 h1[WT];
-            dense<WT * 4, WT>(p.w1[hd], p.b1[hd], W, W, hid, h1, g, h);
-            relu_inplace<WT>(h1);
-            dense<WT * 4, 1>(p.w2[hd], p.b2[hd], W, k, h1, &o0, g, h);
-            if (k > 32) dense<WT * 4, 1>(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, h1, &o1, g, h);
+    // heads that are switched off return their input unchanged (scene/deformation.py:106-146)
+    if (!p.head_on[FDGS_HEAD_POS] && writer) {
+        d.out.xyz[3 * (size_t)n] = xyz[0]; d.out.xyz[3 * (size_t)n + 1] = xyz[1]; d.out.xyz[3 * (size_t)n + 2] = xyz[2];
+    }
+    if (!p.head_on[FDGS_HEAD_SCALE] && writer) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float v = p.scales[3 * (size_t)n + i];
+            d.out.scales[3 * (size_t)n + i] = p.activate ? __expf(v) : v;
         }
+    }
+    if (!p.head_on[FDGS_HEAD_ROT] && writer) {
+        const float4 r = reinterpret_cast<const float4*>(p.rotations)[n];
+        float v0 = r.x, v1 = r.y, v2 = r.z, v3 = r.w;
+        if (p.activate) {
+            const float nrm = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3);
+            const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+            v0 *= inv; v1 *= inv; v2 *= inv; v3 *= inv;
+            if (d.out.rot_norm) d.out.rot_norm[n] = nrm;
+        }
+        reinterpret_cast<float4*>(d.out.rotations)[n] = make_float4(v0, v1, v2, v3);
+    }
+    if (!p.head_on[FDGS_HEAD_OPACITY] && writer) {
+        const float v = p.opacity[n];
+        d.out.opacity[n] = p.activate ? sigmoidf_(v) : v;
+    }
+    if (!p.head_on[FDGS_HEAD_SHS] && live) {
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int row0 = (u < 4 ? 0 : 32) + 8 * (u & 3) + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = row0 + i;
+                v[i] = m < 3 ? p.shs_dc[(size_t)p.shs_dc_stride * n + m] : p.shs_rest[(size_t)p.shs_rest_stride * n + (m - 3)];
+            }
+            *reinterpret_cast<float4*>(d.out.shs + 48 * (size_t)n + row0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+
+    while (hd < FDGS_NUM_HEADS) {
+        const int k = head_k(hd);
+        DenseIL<WT, 1, false, FwdPD<WT>::L2> L2, L2b;
+        L2.setup(p.w2[hd], W, k < 32 ? k : 32, g, h);
+        L2.preload();
+        f32x16 h1[WT];
+        L1.run(p.b1[hd], W, hid, h1, h);
+        relu_inplace<WT>(h1);
+        if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
+        const int nxt = next_head(p.head_on, hd);
+        if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
+        f32x16 o0, o1 = zero16();
+        L2.run(p.b2[hd], k < 32 ? k : 32, h1, &o0, h);
+        if (k > 32) L2b.run(p.b2[hd] + 32, k - 32, h1, &o1, h);
         if (hd == FDGS_HEAD_POS) {
             if (writer) {
                 d.out.xyz[3 * (size_t)n] = xyz[0] + o0[0]; d.out.xyz[3 * (size_t)n + 1] = xyz[1] + o0[1];
@@ -255,6 +436,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd_kernel(DeformDev d) {
                 }
             }
         }
+        hd = nxt;
     }
 }
 
@@ -341,285 +523,460 @@ struct BwdDev {
     float* d_b2[FDGS_NUM_HEADS];
     int F;
     int head_slot[FDGS_NUM_HEADS];  // index of the head's dH1 slab
+    int ntiles;                     // 32-Gaussian tiles (Npad / 32)
 };
 
+// LDS of the backward kernel: per-wave transposed relu(h1) tile [32 gaussians][W + 4] (padded: conflict-free
+// ds_write_b128 / ds_read_b32) + workgroup accumulators of dW2 / db2 for all five heads (59 rows), flushed to global
+// memory once per (persistent) workgroup instead of once per 32 Gaussians.
 template <int WT>
-struct LdsT {
-    static constexpr int STRIDE = WT * 32 + 4;  // padded row: conflict-free ds_write_b128 and ds_read_b32
+struct BwdLds {
+    static constexpr int W = WT * 32;
+    static constexpr int STRIDE = W + 4;
+    static constexpr int TILE_FLOATS = 32 * STRIDE;
+    static constexpr int KSUM = 59;                    // 3 + 3 + 4 + 1 + 48 output rows over the five heads
+    static constexpr int ACC_W = KSUM * W;
+    static constexpr int TOTAL = 4 * TILE_FLOATS + ACC_W + 64;
 };
+__host__ __device__ __forceinline__ int head_row0(int hd) { return hd == 0 ? 0 : hd == 1 ? 3 : hd == 2 ? 6 : hd == 3 ? 10 : 11; }
 
 template <int WT, int FCH>
-__global__ void __launch_bounds__(256, 2) deform_bwd_data_kernel(BwdDev d) {
+__global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     const fdgs_deform_params& p = d.p;
     constexpr int FT = (FCH + 3) / 4;
-    constexpr int STRIDE = LdsT<WT>::STRIDE;
-    __shared__ float lds_all[4 * 32 * STRIDE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
-    float* lds = lds_all + wave * 32 * STRIDE;
-    const int n0 = (blockIdx.x * 4 + wave) * 32;  // first Gaussian of this wave (rows < Npad always exist in scratch)
-    const int n_row = n0 + g;
-    const int n = n_row < p.N ? n_row : p.N - 1;
-    const int W = WT * 32, F = d.F;
-    float q[4], xyz[3];
-    load_query(p, n, q, xyz);
-    f32x16 feat[FT];
-#pragma unroll
-    for (int t = 0; t < FT; t++) feat[t] = zero16();
-    gather_features<FCH>(p, q, h, feat);
-#pragma unroll
-    for (int j = 0; j < FCH; j++)
-        *reinterpret_cast<float4*>(d.s.FEAT + (size_t)n_row * F + 8 * j + 4 * h) =
-            make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
-    f32x16 hid[WT], dhid[WT];
-    dense<FCH, WT>(p.w0, p.b0, F, W, feat, hid, g, h);
-    relu_inplace<WT>(hid);
-#pragma unroll
-    for (int t = 0; t < WT; t++) {
-        dhid[t] = zero16();
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            *reinterpret_cast<float4*>(d.s.RH + (size_t)n_row * W + t * 32 + 8 * u + 4 * h) =
-                make_float4(hid[t][4 * u], hid[t][4 * u + 1], hid[t][4 * u + 2], hid[t][4 * u + 3]);
-    }
-    const float* Grow = d.s.G + (size_t)n_row * GCOLS;
+    using LD = BwdLds<WT>;
+    constexpr int STRIDE = LD::STRIDE, W = WT * 32;
+    __shared__ __attribute__((aligned(16))) float lds_all[LD::TOTAL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g0 = lane & 31, h0 = lane >> 5;
+    float* lds = lds_all + wave * LD::TILE_FLOATS;
+    float* accW2 = lds_all + 4 * LD::TILE_FLOATS;
+    float* accB2 = accW2 + LD::ACC_W;
+    for (int i = threadIdx.x; i < LD::ACC_W + 64; i += 256) accW2[i] = 0.f;
+    __syncthreads();
+    const int F = d.F;
 
-    for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
-        if (!p.head_on[hd]) continue;
-        const int k = head_k(hd), off = head_off(hd);
-        uint32_t mask[WT];  // bit r of mask[t]: h1[t][r] > 0
-        {
-            f32x16 h1[WT];
-            dense<WT * 4, WT>(p.w1[hd], p.b1[hd], W, W, hid, h1, g, h);
+    for (int tile = blockIdx.x * 4 + wave; tile < d.ntiles; tile += gridDim.x * 4) {
+        // opaque per-iteration copies of the lane coordinates: keeps the (hundreds of) loop-invariant weight addresses
+        // from being hoisted out of the tile loop and held in registers across it
+        int g = g0, h = h0;
+        asm volatile("" : "+v"(g), "+v"(h));
+        const int n0 = tile * 32;  // first Gaussian of this wave's tile (rows < Npad always exist in scratch)
+        const int n_row = n0 + g;
+        const int n = n_row < p.N ? n_row : p.N - 1;
+        DenseTrunk<FCH, WT, 2> T0;
+        T0.setup(p.w0, F, g, h);
+        T0.preload();
+        int hd = next_head(p.head_on, -1);
+        DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
+        L1.setup(p.w1[hd], W, W, g, h);   // at least one head is active (checked on the host)
+        L1.preload();
+        float q[4], xyz[3];
+        load_query(p, n, q, xyz);
+        f32x16 feat[FT];
 #pragma unroll
-            for (int t = 0; t < WT; t++) {
-                mask[t] = 0;
+        for (int t = 0; t < FT; t++) feat[t] = zero16();
+        gather_features<FCH>(p, q, h, feat);
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    h1[t][r] = fmaxf(h1[t][r], 0.f);
-                    mask[t] |= (h1[t][r] > 0.f ? 1u : 0u) << r;
+        for (int j = 0; j < FCH; j++)
+            *reinterpret_cast<float4*>(d.s.FEAT + (size_t)n_row * F + 8 * j + 4 * h) =
+                make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
+        f32x16 hid[WT], dhid[WT];
+        T0.run(p.b0, feat, hid, h);
+        relu_inplace<WT>(hid);
+        store_il<WT>(d.s.RH + (size_t)n_row * W, hid, h);
+#pragma unroll
+        for (int t = 0; t < WT; t++) dhid[t] = zero16();
+        const float* Grow = d.s.G + (size_t)n_row * GCOLS;
+
+        while (hd < FDGS_NUM_HEADS) {
+            asm volatile("" : "+v"(g), "+v"(h));   // no hoisting of per-layer address arithmetic out of the head loop
+            const int k = head_k(hd), off = head_off(hd), row0 = head_row0(hd);
+            uint32_t mask[WT];  // bit r of mask[t]: h1[t][r] > 0
+            const int nt2 = k > 32 ? 2 : 1;
+            {
+                f32x16 h1[WT];
+                L1.run(p.b1[hd], W, hid, h1, h);
+#pragma unroll
+                for (int t = 0; t < WT; t++) {
+                    mask[t] = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        h1[t][r] = fmaxf(h1[t][r], 0.f);
+                        mask[t] |= (h1[t][r] > 0.f ? 1u : 0u) << r;
+                    }
                 }
                 // transposed copy relu(h1)[gaussian][feature] for the dW2 product
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    *reinterpret_cast<float4*>(lds + g * STRIDE + t * 32 + 8 * u + 4 * h) =
-                        make_float4(h1[t][4 * u], h1[t][4 * u + 1], h1[t][4 * u + 2], h1[t][4 * u + 3]);
+                store_il<WT>(lds + g * STRIDE, h1, h);
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // ---- dW2[o][in] += sum_g G[g][o] * relu(h1)[g][in]; db2 through a column of ones
-        // (two feature tiles of relu(h1) at a time: keeps the accumulator footprint at 48 VGPRs)
-        for (int ot2 = 0; ot2 * 32 < k; ot2++) {
-            const int o = ot2 * 32 + g;
+            // first operands of the long transposed product in flight before the dW2 block
+            DenseT<WT, WT, true, 4> B1;
+            B1.setup(p.w1[hd], W, W, g, h);
+            B1.preload();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // ---- dW2[o][in] += sum_g G[g][o] * relu(h1)[g][in];  db2[o] += sum_g G[g][o]
+            for (int ot2 = 0; ot2 < nt2; ot2++) {
+                // A-lane (o = 32*ot2 + g, gaussian 2s+h): the head's packed output-gradient rows
+                const int o = ot2 * 32 + g;
+                float ga[16];
 #pragma unroll
-            for (int tb = 0; tb < WT; tb += 2) {
-                f32x16 acc0 = zero16(), acc1 = zero16(), accb = zero16();
-#pragma unroll 4
-                for (int s = 0; s < 16; s++) {
-                    const int gs = 2 * s + h;
-                    const float a = o < k ? d.s.G[(size_t)(n0 + gs) * GCOLS + off + o] : 0.f;
-                    acc0 = mfma32(a, lds[gs * STRIDE + tb * 32 + g], acc0);
-                    acc1 = mfma32(a, lds[gs * STRIDE + (tb + 1) * 32 + g], acc1);
-                    if (tb == 0) accb = mfma32(a, 1.0f, accb);
-                }
+                for (int s = 0; s < 16; s++) ga[s] = o < k ? d.s.G[(size_t)(n0 + 2 * s + h) * GCOLS + off + o] : 0.f;
+                float asum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int orow = ot2 * 32 + frow(0, r, h);
-                    if (orow < k) {
-                        atomicAdd(&d.d_w2[hd][(size_t)orow * W + tb * 32 + g], acc0[r]);
-                        atomicAdd(&d.d_w2[hd][(size_t)orow * W + (tb + 1) * 32 + g], acc1[r]);
-                        if (tb == 0 && g == 0) atomicAdd(&d.d_b2[hd][orow], accb[r]);
+                for (int s = 0; s < 16; s++) asum += ga[s];
+                asum += __shfl_xor(asum, 32, 64);
+                const int kk = k - ot2 * 32;  // valid rows of this 32-row output tile
+                if (h == 0 && g < kk) atomicAdd(&accB2[row0 + ot2 * 32 + g], asum);
+#pragma unroll
+                for (int tb = 0; tb < WT; tb += 2) {   // two feature tiles at a time: 32 accumulator registers
+                    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+                    for (int s = 0; s < 16; s++) {
+                        acc0 = mfma32(ga[s], lds[(2 * s + h) * STRIDE + tb * 32 + g], acc0);
+                        acc1 = mfma32(ga[s], lds[(2 * s + h) * STRIDE + (tb + 1) * 32 + g], acc1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int orow = rho(r, h);
+                        if (orow < kk) {
+                            atomicAdd(&accW2[(row0 + ot2 * 32 + orow) * W + tb * 32 + g], acc0[r]);
+                            atomicAdd(&accW2[(row0 + ot2 * 32 + orow) * W + (tb + 1) * 32 + g], acc1[r]);
+                        }
                     }
                 }
             }
-        }
-        // ---- dh1 = W2^T G_head, masked by relu'(h1)
-        f32x16 dh1[WT];
+            // ---- dh1 = W2^T G_head (k-steps over the head's outputs, two per MFMA), masked by relu'(h1)
+            f32x16 dh1[WT];
 #pragma unroll
-        for (int t = 0; t < WT; t++) dh1[t] = zero16();
-        for (int s = 0; 2 * s < k; s++) {
-            const int o = 2 * s + h;
-            const float b = o < k ? Grow[off + o] : 0.f;
+            for (int t = 0; t < WT; t++) dh1[t] = zero16();
+            {
+                const float* w2p = p.w2[hd] + WT * g;
+                const int nsteps = (k + 1) >> 1;
+                auto ldA = [&](int s) { int o = 2 * s + h; o = o < k ? o : k - 1; return ldv<WT>(w2p + (size_t)o * W); };
+                auto ldB = [&](int s) { const int o = 2 * s + h; return o < k ? Grow[off + o] : 0.f; };
+                AVec<WT> a0 = ldA(0), a1 = ldA(1 < nsteps ? 1 : 0), a2 = ldA(2 < nsteps ? 2 : 0);
+                float b0 = ldB(0), b1 = 1 < nsteps ? ldB(1) : 0.f, b2 = 2 < nsteps ? ldB(2) : 0.f;
+                for (int s = 0; s < nsteps; s++) {
+                    const AVec<WT> a = a0;
+                    const float b = b0;
+                    a0 = a1; b0 = b1; a1 = a2; b1 = b2;
+                    if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
 #pragma unroll
-            for (int t = 0; t < WT; t++) {
-                const float a = o < k ? p.w2[hd][(size_t)o * W + t * 32 + g] : 0.f;
-                dh1[t] = mfma32(a, b, dh1[t]);
+                    for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
+                }
             }
+            float* slab = d.s.DH1 + (size_t)d.head_slot[hd] * d.s.Npad * W;
+#pragma unroll
+            for (int t = 0; t < WT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) dh1[t][r] = ((mask[t] >> r) & 1u) ? dh1[t][r] : 0.f;
+            store_il<WT>(slab + (size_t)n_row * W, dh1, h);
+            // ---- dhid += W1^T dh1
+            B1.run(dh1, dhid);
+            __builtin_amdgcn_wave_barrier();
+            hd = next_head(p.head_on, hd);
+            if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
         }
-        float* slab = d.s.DH1 + (size_t)d.head_slot[hd] * d.s.Npad * W;
+        // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
+        DenseT<WT, FT, false, 4> B0;
+        B0.setup(p.w0, F, F, g, h);
+        B0.preload();
 #pragma unroll
-        for (int t = 0; t < WT; t++) {
+        for (int t = 0; t < WT; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) dh1[t][r] = ((mask[t] >> r) & 1u) ? dh1[t][r] : 0.f;
+            for (int r = 0; r < 16; r++) dhid[t][r] = hid[t][r] > 0.f ? dhid[t][r] : 0.f;
+        store_il<WT>(d.s.DHID + (size_t)n_row * W, dhid, h);
+        f32x16 dfeat[FT];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                *reinterpret_cast<float4*>(slab + (size_t)n_row * W + t * 32 + 8 * u + 4 * h) =
-                    make_float4(dh1[t][4 * u], dh1[t][4 * u + 1], dh1[t][4 * u + 2], dh1[t][4 * u + 3]);
+        for (int t = 0; t < FT; t++) dfeat[t] = zero16();
+        B0.run(dhid, dfeat);
+#pragma unroll
+        for (int j = 0; j < FCH; j++)
+            *reinterpret_cast<float4*>(d.s.DFEAT + (size_t)n_row * F + 8 * j + 4 * h) =
+                make_float4(dfeat[j / 4][4 * (j % 4)], dfeat[j / 4][4 * (j % 4) + 1], dfeat[j / 4][4 * (j % 4) + 2],
+                            dfeat[j / 4][4 * (j % 4) + 3]);
+    }
+    // flush the workgroup's dW2 / db2 sums
+    __syncthreads();
+    for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
+        if (!p.head_on[hd]) continue;
+        const int k = head_k(hd), row0 = head_row0(hd);
+        for (int i = threadIdx.x; i < k * W; i += 256) {
+            const float v = accW2[row0 * W + i];
+            if (v != 0.f) atomicAdd(&d.d_w2[hd][i], v);
         }
-        // ---- dhid += W1^T dh1
-        dense_bwd_data<WT, WT>(p.w1[hd], W, W, dh1, dhid, g, h);
-        __builtin_amdgcn_wave_barrier();
+        if ((int)threadIdx.x < k) atomicAdd(&d.d_b2[hd][threadIdx.x], accB2[row0 + threadIdx.x]);
     }
-    // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
-#pragma unroll
-    for (int t = 0; t < WT; t++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) dhid[t][r] = hid[t][r] > 0.f ? dhid[t][r] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            *reinterpret_cast<float4*>(d.s.DHID + (size_t)n_row * W + t * 32 + 8 * u + 4 * h) =
-                make_float4(dhid[t][4 * u], dhid[t][4 * u + 1], dhid[t][4 * u + 2], dhid[t][4 * u + 3]);
-    }
-    f32x16 dfeat[FT];
-#pragma unroll
-    for (int t = 0; t < FT; t++) dfeat[t] = zero16();
-    dense_bwd_data<WT, FT>(p.w0, F, F, dhid, dfeat, g, h);
-#pragma unroll
-    for (int j = 0; j < FCH; j++)
-        *reinterpret_cast<float4*>(d.s.DFEAT + (size_t)n_row * F + 8 * j + 4 * h) =
-            make_float4(dfeat[j / 4][4 * (j % 4)], dfeat[j / 4][4 * (j % 4) + 1], dfeat[j / 4][4 * (j % 4) + 2],
-                        dfeat[j / 4][4 * (j % 4) + 3]);
 }
 
 // ------------------------------------------------------------------------------------------------ D3 weight grads
-// dW[m][c] += sum_n DY[n][m] * X[n][c]   (m < 32*MT rows of DY, c < ncols of X), db[m] += sum_n DY[n][m]
+// dW[m][c] += sum_n DY[n][m] * X[n][c]   (m < W rows of DY, c < ncols of X), db[m] += sum_n DY[n][m];  K = #Gaussians.
+// One wave owns the WHOLE [W x ncols] product for its slice of Gaussians (16 accumulator tiles = 256 AGPRs at W = 128,
+// one wave per SIMD): with the interleaved tile mapping (row m = WT*i + a, column c = WT*j + b) a k-step of two Gaussians
+// needs exactly ONE 16-byte load of DY[n][WT*g ..] and ONE of X[n][WT*g ..] per lane for its 16 MFMAs -- both
+// 512-byte coalesced rows, prefetched WG_PD steps ahead.  The four waves of a workgroup split the workgroup's Gaussians,
+// meet in an LDS accumulator (ds_add_f32) and flush each weight once per workgroup with coalesced global atomics.
+// (Round-1 kernel: one dword load per MFMA operand, 4 MFMAs per vmcnt(0) -> 36 % MFMA utilisation.)
 struct WgradJob {
     const float* DY; const float* X; float* dW; float* db;
     int ldx, ncols, ldw;
+    int first_block, nblocks, chunk;   // workgroups [first_block, first_block + nblocks) each take `chunk` Gaussians
 };
 struct WgradArgs {
     WgradJob job[FDGS_NUM_HEADS + 1];
-    int njobs, Npad, W, chunk;
+    int njobs, Npad, W;
 };
-template <int WT>
-__global__ void __launch_bounds__(256, 2) deform_wgrad_kernel(WgradArgs a) {
-    const WgradJob J = a.job[blockIdx.y];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
-    constexpr int WAVES_PER_MT = 4 / WT;  // WT=4: one wave per row tile; WT=2: two waves split K
-    const int mt = wave % WT, ksub = wave / WT;
-    int n_begin = blockIdx.x * a.chunk, n_end = n_begin + a.chunk;
-    if (n_end > a.Npad) n_end = a.Npad;
-    const int span = (n_end - n_begin) / WAVES_PER_MT;  // chunk is a multiple of 4
-    n_begin += ksub * span;
-    n_end = n_begin + span;
-    const int CT = (J.ncols + 31) / 32;
-    f32x16 acc[4];
+constexpr int WG_PD = 3;
+
+// COLS_IL: X has exactly W columns, column mapping interleaved (vector loads); else tile mapping c = 32*b + j with
+// CT = ceil(ncols/32) dword loads per k-step (the small trunk product, ncols = C*L).
+template <int WT, int CT, bool COLS_IL>
+__device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin, int n_end, float* ldsW, float* ldsB, int g, int h) {
+    constexpr int BV = COLS_IL ? WT : 1, NB = COLS_IL ? 1 : CT;
+    f32x16 acc[WT][CT];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = zero16();
-    float asum = 0.f;
-    const int W = a.W;
-    const bool c0 = g < J.ncols, c1 = 32 + g < J.ncols, c2 = 64 + g < J.ncols, c3 = 96 + g < J.ncols;
-#pragma unroll 8
-    for (int n = n_begin + h; n < n_end; n += 2) {
-        const float av = J.DY[(size_t)n * W + mt * 32 + g];
-        const float* xr = J.X + (size_t)n * J.ldx + g;
-        const float b0 = c0 ? xr[0] : 0.f;
-        const float b1 = c1 ? xr[32] : 0.f;
-        const float b2 = c2 ? xr[64] : 0.f;
-        const float b3 = c3 ? xr[96] : 0.f;
-        asum += av;
-        acc[0] = mfma32(av, b0, acc[0]);
-        if (CT > 1) acc[1] = mfma32(av, b1, acc[1]);
-        if (CT > 2) acc[2] = mfma32(av, b2, acc[2]);
-        if (CT > 3) acc[3] = mfma32(av, b3, acc[3]);
+    for (int a = 0; a < WT; a++)
+#pragma unroll
+        for (int b = 0; b < CT; b++) acc[a][b] = zero16();
+    float asum[WT];
+#pragma unroll
+    for (int a = 0; a < WT; a++) asum[a] = 0.f;
+    const float* ap = J.DY + (size_t)(n_begin + h) * W + WT * g;
+    const float* bp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        int col = COLS_IL ? WT * g : 32 * b + g;
+        col = col < J.ncols ? col : J.ncols - 1;
+        bp[b] = J.X + (size_t)(n_begin + h) * J.ldx + col;
     }
+    const int nsteps = (n_end - n_begin) >> 1;   // chunk lengths are even
+    AVec<WT> abuf[WG_PD];
+    AVec<BV> bbuf[WG_PD][NB];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (t < CT) {
-            const int col = t * 32 + g;
-            if (col < J.ncols) {
+    for (int s = 0; s < WG_PD; s++) {
+        const int ss = s < nsteps ? s : 0;
+        abuf[s] = ldv<WT>(ap + (size_t)ss * 2 * W);
 #pragma unroll
-                for (int r = 0; r < 16; r++) atomicAdd(&J.dW[(size_t)frow(mt, r, h) * J.ldw + col], acc[t][r]);
+        for (int b = 0; b < NB; b++) bbuf[s][b] = ldv<BV>(bp[b] + (size_t)ss * 2 * J.ldx);
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += WG_PD) {
+#pragma unroll
+        for (int u = 0; u < WG_PD; u++) {
+            const int s = s0 + u;
+            if (s < nsteps) {
+                const AVec<WT> av = abuf[u];
+                AVec<BV> bv[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++) bv[b] = bbuf[u][b];
+                const int sn = s + WG_PD < nsteps ? s + WG_PD : s;   // tail: harmless re-load of a valid row
+                abuf[u] = ldv<WT>(ap + (size_t)sn * 2 * W);
+#pragma unroll
+                for (int b = 0; b < NB; b++) bbuf[u][b] = ldv<BV>(bp[b] + (size_t)sn * 2 * J.ldx);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < WT; a++) asum[a] += av.v[a];
+#pragma unroll
+                for (int a = 0; a < WT; a++)
+#pragma unroll
+                    for (int b = 0; b < CT; b++) acc[a][b] = mfma32(av.v[a], COLS_IL ? bv[0].v[b] : bv[b].v[0], acc[a][b]);
             }
         }
     }
-    asum += __shfl_xor(asum, 32, 64);
-    if (h == 0) atomicAdd(&J.db[mt * 32 + g], asum);
+    // workgroup reduction in LDS: ldsW[m * ldl + c], ldl = 32*CT
+    constexpr int LDL = 32 * CT;
+#pragma unroll
+    for (int a = 0; a < WT; a++)
+#pragma unroll
+        for (int b = 0; b < CT; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = WT * rho(r, h) + a;
+                const int c = COLS_IL ? WT * g + b : 32 * b + g;
+                atomicAdd(&ldsW[m * LDL + c], acc[a][b][r]);
+            }
+#pragma unroll
+    for (int a = 0; a < WT; a++) {
+        float v = asum[a];
+        v += __shfl_xor(v, 32, 64);
+        if (h == 0) atomicAdd(&ldsB[WT * g + a], v);
+    }
+}
+
+template <int WT>
+__global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
+    constexpr int W = WT * 32;
+    __shared__ float lds[W * W + W];
+    // job of this workgroup
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < FDGS_NUM_HEADS + 1; q++)
+        if (q < a.njobs && (int)blockIdx.x >= a.job[q].first_block) j = q;
+    const WgradJob J = a.job[j];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
+    for (int i = threadIdx.x; i < W * W + W; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    const int blk = (int)blockIdx.x - J.first_block;
+    int n_begin = blk * J.chunk, n_end = n_begin + J.chunk;
+    if (n_end > a.Npad) n_end = a.Npad;
+    // four waves split the chunk (multiples of 2 Gaussians)
+    const int len = n_end > n_begin ? n_end - n_begin : 0;
+    const int per = ((len / 4) + 1) & ~1;
+    int wb = n_begin + wave * per, we = wb + per;
+    if (wb > n_end) wb = n_end;
+    if (we > n_end) we = n_end;
+    float* ldsW = lds;
+    float* ldsB = lds + W * W;
+    const int CTn = (J.ncols + 31) / 32;
+    if (we > wb) {
+        if (J.ncols == W) wgrad_wave<WT, WT, true>(J, W, wb, we, ldsW, ldsB, g, h);
+        else if (CTn == 1) wgrad_wave<WT, 1, false>(J, W, wb, we, ldsW, ldsB, g, h);
+        else if (CTn == 2) wgrad_wave<WT, 2, false>(J, W, wb, we, ldsW, ldsB, g, h);
+        else if (CTn == 3) wgrad_wave<WT, 3, false>(J, W, wb, we, ldsW, ldsB, g, h);
+        else if constexpr (WT != 4) wgrad_wave<WT, 4, false>(J, W, wb, we, ldsW, ldsB, g, h);   // (W = 128, 128 columns) is the interleaved case
+    }
+    __syncthreads();
+    const int ldl = J.ncols == W ? W : 32 * CTn;
+    for (int i = threadIdx.x; i < W * ldl; i += 256) {
+        const int m = i / ldl, c = i - m * ldl;
+        const float v = ldsW[i];
+        if (c < J.ncols && v != 0.f) atomicAdd(&J.dW[(size_t)m * J.ldw + c], v);
+    }
+    if ((int)threadIdx.x < W) atomicAdd(&J.db[threadIdx.x], ldsB[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ D4 plane grads
+// lanes <-> (x-corner, channel) of one Gaussian, so every atomic instruction covers whole 64/128-B texel lines.
+// When every Gaussian shares one frame time (render()), all of them hit the SAME two rows of the three time planes
+// (x,t),(y,t),(z,t): 50 % of the plane-gradient atomics land on ~128 hot lines (5 G float-atomics/s measured vs 20 G/s
+// scattered).  Those planes are therefore privatised per workgroup in LDS: the two time rows receive the same sum
+// scaled by the two (uniform) time weights, so ONE LDS tile [res_a][C] per plane accumulates sum(dv * wx) with
+// ds_add_f32 and is flushed once per workgroup with coalesced global atomics (x w_t0 and x w_t1).
 struct PlaneGradArgs {
     fdgs_deform_params p;
     const float* DFEAT;
     float* d_planes[FDGS_MAX_LEVELS][6];
     float* d_xyz;
     int F;
+    int lds_off[FDGS_MAX_LEVELS][3];  // float offset of the LDS tile of time plane k = 2,4,5 (axis a = 0,1,2); -1: global atomics
+    int lds_floats;
+    int per_block;                    // Gaussians per workgroup
 };
+constexpr int PG_THREADS = 512;
+__host__ __device__ __forceinline__ int time_plane_slot(int k) { return k == 2 ? 0 : (k == 4 ? 1 : (k == 5 ? 2 : -1)); }
+
 template <int C>
-__global__ void __launch_bounds__(256) deform_plane_grad_kernel(PlaneGradArgs a) {
+__global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGradArgs a) {
     const fdgs_deform_params& p = a.p;
-    constexpr int LPG = 2 * C, GPW = 64 / LPG;
-    const int lane = threadIdx.x & 63;
+    extern __shared__ float4 pg_lds4[];
+    float* lds = reinterpret_cast<float*>(pg_lds4);
+    constexpr int LPG = 2 * C, GPW = 64 / LPG, GPB = (PG_THREADS / 64) * GPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ch = lane % C, xc = (lane / C) & 1, gsub = lane / LPG;
-    const int n_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GPW + gsub;
-    const bool live = n_raw < p.N;
-    const int n = live ? n_raw : p.N - 1;
-    float q[4], xyz[3];
-    load_query(p, n, q, xyz);
-    float dq[3] = {0.f, 0.f, 0.f};
-    for (int lvl = 0; lvl < p.L; lvl++) {
-        const float df = live ? a.DFEAT[(size_t)n * a.F + lvl * C + ch] : 0.f;
-        float vk[6], sk[6], tk[6], wA[6], wB[6], dsx[6], dsy[6];
-        size_t oA[6], oB[6];
+    for (int i = threadIdx.x; i < a.lds_floats; i += PG_THREADS) lds[i] = 0.f;
+    __syncthreads();
+    const int n_begin = blockIdx.x * a.per_block;
+    const int n_end = n_begin + a.per_block < p.N ? n_begin + a.per_block : p.N;
+    for (int nb = n_begin; nb < n_end; nb += GPB) {
+        const int n_raw = nb + wave * GPW + gsub;
+        const bool live = n_raw < n_end;
+        const int n = live ? n_raw : n_end - 1;
+        float q[4], xyz[3];
+        load_query(p, n, q, xyz);
+        float dq[3] = {0.f, 0.f, 0.f};
+        for (int lvl = 0; lvl < p.L; lvl++) {
+            const float df = live ? a.DFEAT[(size_t)n * a.F + lvl * C + ch] : 0.f;
+            float vk[6], sk[6], tk[6], wA[6], wB[6], wX[6], dsx[6], dsy[6];
+            int oA[6], oB[6], oX[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            int ax, bx;
-            plane_axes(k, ax, bx);
-            const int Wd = p.res[lvl][ax], Hd = p.res[lvl][bx];
-            const AxisSample sx = axis_sample(q[ax], Wd), sy = axis_sample(q[bx], Hd);
-            const int xi = xc ? sx.i1 : sx.i0;
-            const float wx = xc ? sx.w1 : sx.w0;
-            oA[k] = (size_t)(sy.i0 * Wd + xi) * C + ch;
-            oB[k] = (size_t)(sy.i1 * Wd + xi) * C + ch;
-            const float v0 = p.planes[lvl][k][oA[k]], v1 = p.planes[lvl][k][oB[k]];
-            sk[k] = sy.w0 * v0 + sy.w1 * v1;             // d/d(ix) carries sign(xc)
-            tk[k] = wx * (v1 - v0);                      // d/d(iy)
-            float part = wx * sk[k];
-            if (C == 16) {
-                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            } else {
-                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            for (int k = 0; k < 6; k++) {
+                int ax, bx;
+                plane_axes(k, ax, bx);
+                const int Wd = p.res[lvl][ax], Hd = p.res[lvl][bx];
+                const AxisSample sx = axis_sample(q[ax], Wd), sy = axis_sample(q[bx], Hd);
+                const int xi = xc ? sx.i1 : sx.i0;
+                const float wx = xc ? sx.w1 : sx.w0;
+                oX[k] = xi * C + ch;
+                oA[k] = (sy.i0 * Wd + xi) * C + ch;
+                oB[k] = (sy.i1 * Wd + xi) * C + ch;
+                const float v0 = p.planes[lvl][k][oA[k]], v1 = p.planes[lvl][k][oB[k]];
+                sk[k] = sy.w0 * v0 + sy.w1 * v1;             // d/d(ix) carries sign(xc)
+                tk[k] = wx * (v1 - v0);                      // d/d(iy)
+                float part = wx * sk[k];
+                if (C == 16) {
+                    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                    part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                } else {
+                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                    part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+                vk[k] = part;
+                wX[k] = wx; wA[k] = wx * sy.w0; wB[k] = wx * sy.w1;
+                dsx[k] = sx.dscale; dsy[k] = sy.dscale;
             }
-            vk[k] = part;
-            wA[k] = wx * sy.w0; wB[k] = wx * sy.w1;
-            dsx[k] = sx.dscale; dsy[k] = sy.dscale;
+            float pre[6], suf[6];
+            pre[0] = 1.f; suf[5] = 1.f;
+#pragma unroll
+            for (int k = 1; k < 6; k++) pre[k] = pre[k - 1] * vk[k - 1];
+#pragma unroll
+            for (int k = 4; k >= 0; k--) suf[k] = suf[k + 1] * vk[k + 1];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                int ax, bx;
+                plane_axes(k, ax, bx);
+                const float dv = df * pre[k] * suf[k];
+                float* dP = a.d_planes[lvl][k];
+                const int slot = time_plane_slot(k);
+                const int loff = slot >= 0 ? a.lds_off[lvl][slot] : -1;
+                if (dP && live) {
+                    if (loff >= 0) {
+                        atomicAdd(&lds[loff + oX[k]], dv * wX[k]);   // ds_add_f32
+                    } else {
+                        atomicAdd(&dP[oA[k]], dv * wA[k]);
+                        atomicAdd(&dP[oB[k]], dv * wB[k]);
+                    }
+                }
+                const float gx = dv * (xc ? sk[k] : -sk[k]) * dsx[k];
+                const float gy = dv * tk[k] * dsy[k];
+                if (ax < 3) dq[ax] += gx;   // ax in {0,1,2}
+                if (bx < 3) dq[bx] += gy;   // bx == 3 is time: no gradient
+            }
         }
-        float pre[6], suf[6];
-        pre[0] = 1.f; suf[5] = 1.f;
+        if (a.d_xyz) {
 #pragma unroll
-        for (int k = 1; k < 6; k++) pre[k] = pre[k - 1] * vk[k - 1];
-#pragma unroll
-        for (int k = 4; k >= 0; k--) suf[k] = suf[k + 1] * vk[k + 1];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            int ax, bx;
-            plane_axes(k, ax, bx);
-            const float dv = df * pre[k] * suf[k];
-            float* dP = a.d_planes[lvl][k];
-            if (dP && live) {
-                atomicAdd(&dP[oA[k]], dv * wA[k]);
-                atomicAdd(&dP[oB[k]], dv * wB[k]);
+            for (int i = 0; i < 3; i++) {
+                float v = dq[i];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                if (LPG == 64) v += __shfl_xor(v, 32, 64);
+                dq[i] = v;
             }
-            const float gx = dv * (xc ? sk[k] : -sk[k]) * dsx[k];
-            const float gy = dv * tk[k] * dsy[k];
-            if (ax < 3) dq[ax] += gx;   // ax in {0,1,2}
-            if (bx < 3) dq[bx] += gy;   // bx == 3 is time: no gradient
+            if (live && (lane % LPG) == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) a.d_xyz[3 * (size_t)n + i] += dq[i] * (2.0f / (p.aabb[3 + i] - p.aabb[i]));
+            }
         }
     }
-    if (a.d_xyz) {
+    if (a.lds_floats == 0) return;
+    __syncthreads();
+    // flush the privatised time planes: rows t0, t1 of plane (a, t) get the tile scaled by the two time weights
+    for (int lvl = 0; lvl < p.L; lvl++) {
+        const AxisSample st = axis_sample(p.time_scalar, p.res[lvl][3]);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            float v = dq[i];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            if (LPG == 64) v += __shfl_xor(v, 32, 64);
-            dq[i] = v;
-        }
-        if (live && (lane % LPG) == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) a.d_xyz[3 * (size_t)n + i] += dq[i] * (2.0f / (p.aabb[3 + i] - p.aabb[i]));
+        for (int slot = 0; slot < 3; slot++) {
+            const int loff = a.lds_off[lvl][slot];
+            if (loff < 0) continue;
+            const int k = slot == 0 ? 2 : (slot == 1 ? 4 : 5);
+            const int Wd = p.res[lvl][slot];
+            float* dP = a.d_planes[lvl][k];
+            float* r0 = dP + (size_t)st.i0 * Wd * C;
+            float* r1 = dP + (size_t)st.i1 * Wd * C;
+            for (int i = threadIdx.x; i < Wd * C; i += PG_THREADS) {
+                const float v = lds[loff + i];
+                if (v != 0.f) {
+                    atomicAdd(&r0[i], v * st.w0);
+                    atomicAdd(&r1[i], v * st.w1);
+                }
+            }
         }
     }
 }
@@ -650,8 +1007,12 @@ template <template <int, int> class Launcher, typename Arg>
 static int dispatch_wf(int W, int F, hipStream_t stream, int blocks, const Arg& arg) {
 #define FDGS_CASE(WT_, FCH_) \
     if (W == WT_ * 32 && F == FCH_ * 8) { Launcher<WT_, FCH_>::go(stream, blocks, arg); return FDGS_OK; }
+#ifdef FDGS_DEV_ONLY_44   // development builds: only the (net_width 128, C*L 32) instance, for quick ISA inspection
+    FDGS_CASE(4, 4)
+#else
     FDGS_CASE(2, 4) FDGS_CASE(2, 6) FDGS_CASE(2, 8) FDGS_CASE(2, 12) FDGS_CASE(2, 16)
     FDGS_CASE(4, 4) FDGS_CASE(4, 6) FDGS_CASE(4, 8) FDGS_CASE(4, 12) FDGS_CASE(4, 16)
+#endif
 #undef FDGS_CASE
     return fail(FDGS_E_INVALID, "%s", "unsupported (net_width, C*L) combination");
 }
@@ -663,7 +1024,20 @@ struct FwdLauncher {
 };
 template <int WT, int FCH>
 struct BwdLauncher {
-    static void go(hipStream_t s, int blocks, const BwdDev& d) {
+    // persistent: as many workgroups as are co-resident (each keeps dW2/db2 sums in LDS), tiles handed out round-robin
+    static void go(hipStream_t s, int max_blocks, const BwdDev& d) {
+        static int resident = 0;
+        if (resident == 0) {
+            int dev = 0, cus = 256, per_cu = 1;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, deform_bwd_data_kernel<WT, FCH>, 256, 0) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            resident = cus * per_cu;
+        }
+        int blocks = tunable("FDGS_D2_WGS", resident);
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL((deform_bwd_data_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
@@ -741,7 +1115,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
     BwdDev bd;
-    bd.p = *p; bd.s = s; bd.F = (int)F;
+    bd.p = *p; bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32);
     int slot = 0;
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
         bd.d_w2[hd] = g->d_w2[hd]; bd.d_b2[hd] = g->d_b2[hd];
@@ -768,15 +1142,29 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         J.DY = s.DHID; J.X = s.FEAT; J.dW = g->d_w0; J.db = g->d_b0; J.ldx = (int)F; J.ncols = (int)F; J.ldw = (int)F;
     }
     wa.njobs = nj;
-    int ksplit = 1024 / nj;
-    if (ksplit < 1) ksplit = 1;
-    int chunk = (int)((Np + ksplit - 1) / ksplit);
-    chunk = (chunk + 3) / 4 * 4;
-    if (chunk < 64) chunk = 64;
-    wa.chunk = chunk;
-    const int kblocks = (int)((Np + chunk - 1) / chunk);
-    if (W == 128) { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<4>), dim3(kblocks, nj), dim3(256), 0, stream, wa); }
-    else { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<2>), dim3(kblocks, nj), dim3(256), 0, stream, wa); }
+    {
+        // one workgroup per CU; workgroups are shared out in proportion to the MFMA work of each job
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int total_wgs = tunable("FDGS_WGRAD_WGS", cus);
+        int work[FDGS_NUM_HEADS + 1], total_work = 0;
+        for (int j = 0; j < nj; j++) { work[j] = (wa.job[j].ncols + 31) / 32; total_work += work[j]; }
+        int first = 0;
+        for (int j = 0; j < nj; j++) {
+            WgradJob& J = wa.job[j];
+            int nb = (int)(((long long)total_wgs * work[j] + total_work / 2) / total_work);
+            if (nb < 1) nb = 1;
+            int chunk = (int)((Np + nb - 1) / nb);
+            chunk = (chunk + 7) / 8 * 8;        // four waves x two Gaussians per MFMA k-step
+            if (chunk < 64) chunk = 64;
+            nb = (int)((Np + chunk - 1) / chunk);
+            J.first_block = first; J.nblocks = nb; J.chunk = chunk;
+            first += nb;
+        }
+        if (W == 128) { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<4>), dim3(first), dim3(256), 0, stream, wa); }
+        else { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<2>), dim3(first), dim3(256), 0, stream, wa); }
+    }
     FDGS_LAUNCH_CHECK("deform_wgrad", 0, stream);
     // plane + coordinate gradients
     bool any_plane = g->d_xyz != nullptr;
@@ -785,8 +1173,33 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     for (int l = 0; l < p->L; l++)
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
-        if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<16>), dim3(cdiv(p->N, 8)), dim3(256), 0, stream, ga); }
-        else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<32>), dim3(cdiv(p->N, 4)), dim3(256), 0, stream, ga); }
+        // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
+        const int lds_budget = tunable("FDGS_PG_LDS", 1) ? 64 * 1024 : 0;  // bytes per workgroup (2 workgroups / CU)
+        int used = 0;
+        for (int l = 0; l < FDGS_MAX_LEVELS; l++)
+            for (int sl = 0; sl < 3; sl++) ga.lds_off[l][sl] = -1;
+        if (!p->time) {
+            for (int l = 0; l < p->L; l++) {
+                int need = 0;
+                for (int sl = 0; sl < 3; sl++) need += p->res[l][sl] * p->C;
+                const int kk[3] = {2, 4, 5};
+                bool wanted = true;
+                for (int sl = 0; sl < 3; sl++) wanted = wanted && g->d_planes[l][kk[sl]];
+                if (!wanted || (size_t)(used + need) * 4 > (size_t)lds_budget) continue;
+                for (int sl = 0; sl < 3; sl++) { ga.lds_off[l][sl] = used; used += p->res[l][sl] * p->C; }
+            }
+        }
+        ga.lds_floats = used;
+        const int gpb = (PG_THREADS / 64) * (64 / (2 * p->C));       // Gaussians per workgroup iteration
+        int nwg = tunable("FDGS_PG_WGS", 512);                        // ~2 workgroups per CU
+        int per_block = cdiv(p->N, nwg);
+        per_block = cdiv(per_block, gpb) * gpb;
+        if (per_block < gpb) per_block = gpb;
+        ga.per_block = per_block;
+        const int blocks = cdiv(p->N, per_block);
+        const size_t lds_bytes = (size_t)used * 4;
+        if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<16>), dim3(blocks), dim3(PG_THREADS), lds_bytes, stream, ga); }
+        else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<32>), dim3(blocks), dim3(PG_THREADS), lds_bytes, stream, ga); }
         FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
     }
     return FDGS_OK;

@@ -114,7 +114,24 @@ struct PreBwdArgs {
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.P) return;
-    if (a.tiles[i] == 0) return;
+    if (a.tiles[i] == 0) {
+        // culled / zero-area Gaussians: every output row is written here (zeros), so the caller needs no memsets
+        a.dL_dmeans2D[3 * (size_t)i] = 0.f; a.dL_dmeans2D[3 * (size_t)i + 1] = 0.f; a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+        a.dL_dopacity[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { a.dL_dcolors[3 * (size_t)i + k] = 0.f; a.dL_dmeans3D[3 * (size_t)i + k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
+        if (a.shs) {
+            float* out = a.dL_dsh + (size_t)i * a.M * 3;
+            for (int k = 0; k < a.M * 3; k++) out[k] = 0.f;
+        }
+        if (!a.has_cov_precomp) {
+            a.dL_dscales[3 * (size_t)i] = 0.f; a.dL_dscales[3 * (size_t)i + 1] = 0.f; a.dL_dscales[3 * (size_t)i + 2] = 0.f;
+            reinterpret_cast<float4*>(a.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     CamConst c;
     load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
     float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
@@ -127,6 +144,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
     float gx = g0.x * 0.5f * (float)a.W, gy = g0.y * 0.5f * (float)a.H;
     a.dL_dmeans2D[3 * (size_t)i] = gx;
     a.dL_dmeans2D[3 * (size_t)i + 1] = gy;
+    a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
     a.dL_dopacity[i] = g1.y;
     float drgb[3] = {g1.z, g1.w, g2.x};
     a.dL_dcolors[3 * (size_t)i] = drgb[0]; a.dL_dcolors[3 * (size_t)i + 1] = drgb[1]; a.dL_dcolors[3 * (size_t)i + 2] = drgb[2];
@@ -142,6 +160,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
         int nc = (c.D + 1) * (c.D + 1);
         float* out = a.dL_dsh + (size_t)i * a.M * 3;
         for (int k = 0; k < nc * 3; k++) out[k] = dsh[k];
+        for (int k = nc * 3; k < a.M * 3; k++) out[k] = 0.f;   // coefficients above the active degree
     }
     a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
     a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];

@@ -264,15 +264,12 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     hipStream_t stream = (hipStream_t)stream_;
     const size_t P = (size_t)p->P;
     if (P == 0) return FDGS_OK;
-    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dmeans2D, 0, P * 12, stream));
-    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dmeans3D, 0, P * 12, stream));
-    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dopacity, 0, P * 4, stream));
-    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcolors, 0, P * 12, stream));
-    FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dcov3D, 0, P * 24, stream));
+    // the per-Gaussian outputs are written for every Gaussian by preprocess_bwd; only the atomic accumulator needs zeros
     FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_acc, 0, P * 64, stream));
-    if (g->dL_dsh) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dsh, 0, P * (size_t)p->sh_coeffs * 12, stream));
-    if (g->dL_dscales) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dscales, 0, P * 12, stream));
-    if (g->dL_drotations) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_drotations, 0, P * 16, stream));
+    if (p->cov3D_precomp) {   // scale/rotation gradients do not exist on this path: hand back zeros if buffers were given
+        if (g->dL_dscales) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dscales, 0, P * 12, stream));
+        if (g->dL_drotations) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_drotations, 0, P * 16, stream));
+    }
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
     ImgLayout il = img_layout(p->W, p->H);

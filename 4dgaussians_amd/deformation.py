@@ -278,21 +278,33 @@ class _DeformFunction(torch.autograd.Function):
         gx, gs, gr, go, gsh = c(g_xyz), c(g_sc), c(g_rot), c(g_op), c(g_sh)
         g.g_xyz, g.g_scales, g.g_rotations, g.g_opacity, g.g_shs = ptr(gx), ptr(gs), ptr(gr), ptr(go), ptr(gsh)
         g.out_scales, g.out_rotations, g.out_opacity, g.rot_norm = ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_norm)
-        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
-        d_xyz, d_sc, d_rot, d_op = z(N, 3), z(N, 3), z(N, 4), z(N, 1)
+        # every outgoing gradient is accumulated into (+=) by the kernels: ONE zero-filled arena, carved into views
+        # (40 separate torch.zeros launches cost more than the fill itself at 150 frames/s)
+        shapes = [(N, 3), (N, 3), (N, 4), (N, 1)]
+        shapes += [(N, 16, 3)] if sh_b is None else [(N, 1, 3), (N, 15, 3)]
+        n_fixed = len(shapes)
+        shapes += [(1, s_[2], s_[3], s_[1]) for s_ in ctx.plane_shapes]          # channels-last memory order
+        shapes += [tuple(m.shape) for m in mlp]
+        sizes = [(int(torch.Size(s_).numel()) + 63) // 64 * 64 for s_ in shapes]  # 256-B aligned slices
+        arena = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        views, off = [], 0
+        for s_, n_ in zip(shapes, sizes):
+            views.append(arena[off:off + int(torch.Size(s_).numel())].view(s_))
+            off += n_
+        d_xyz, d_sc, d_rot, d_op = views[:4]
         if sh_b is None:
-            d_sha, d_shb = z(N, 16, 3), None
+            d_sha, d_shb = views[4], None
             g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_sha.data_ptr() + 12
         else:
-            d_sha, d_shb = z(N, 1, 3), z(N, 15, 3)
+            d_sha, d_shb = views[4], views[5]
             g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_shb.data_ptr()
         g.d_xyz, g.d_scales, g.d_rotations, g.d_opacity = ptr(d_xyz), ptr(d_sc), ptr(d_rot), ptr(d_op)
-        d_planes = [torch.empty(s, device=dev, dtype=torch.float32, memory_format=torch.channels_last).zero_()
-                    for s in ctx.plane_shapes]
+        nplanes = len(ctx.plane_shapes)
+        d_planes = [v.permute(0, 3, 1, 2) for v in views[n_fixed:n_fixed + nplanes]]  # logical [1,C,H,W], channels_last
         for l in range(cfg["L"]):
             for k in range(6):
                 g.d_planes[l][k] = d_planes[l * 6 + k].data_ptr()
-        d_mlp = [torch.zeros_like(m) for m in mlp]
+        d_mlp = list(views[n_fixed + nplanes:])
         g.d_w0, g.d_b0 = d_mlp[0].data_ptr(), d_mlp[1].data_ptr()
         for h in range(NUM_HEADS):
             g.d_w1[h], g.d_b1[h] = d_mlp[2 + 4 * h].data_ptr(), d_mlp[3 + 4 * h].data_ptr()

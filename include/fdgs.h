@@ -98,7 +98,7 @@ int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom,
 typedef struct fdgs_raster_grads {
     const float* dL_dcolor;  /* [3,H,W] */
     const float* dL_ddepth;  /* opt [1,H,W] */
-    /* outputs, all written (zero-filled first) by fdgs_raster_bwd */
+    /* outputs: every row is written by fdgs_raster_bwd (zeros for culled Gaussians); no caller-side zero fill needed */
     float* dL_dmeans2D;      /* [P,3]: x,y in NDC units, z = 0 (the reference's viewspace_points.grad) */
     float* dL_dmeans3D;      /* [P,3] */
     float* dL_dopacity;      /* [P] */

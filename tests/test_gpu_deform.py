@@ -19,7 +19,7 @@ def _fdgs():
     return importlib.import_module("4dgaussians_amd")
 
 
-def _net_and_inputs(cfg, n, seed, dev, overrides=None, safe=True):
+def _net_and_inputs(cfg, n, seed, dev, overrides=None, safe=True, fixed_time=None):
     fd = _fdgs()
     torch.manual_seed(seed)
     args = synthetic.deform_args(cfg, **(overrides or {}))
@@ -36,6 +36,8 @@ def _net_and_inputs(cfg, n, seed, dev, overrides=None, safe=True):
     shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
     t = torch.rand(m, 1, generator=gen)
     t[:4] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])
+    if fixed_time is not None:
+        t[:] = float(fixed_time)
     ins = [xyz, g["scaling"], g["rotation"], g["opacity"], shs, t]
     if safe:
         # keep Gaussians that sit at least 1e-4 away from every ReLU kink / texel boundary: there float32 rounding
@@ -54,9 +56,20 @@ CFGS = [("dnerf_bouncingballs", 1000), ("hypernerf_default", 257), ("dynerf_defa
 @pytest.mark.parametrize("cfg,n", CFGS)
 @pytest.mark.parametrize("activate", [False, True])
 def test_deform_forward_backward_parity(cfg, n, activate):
+    _parity(cfg, n, activate)
+
+
+@pytest.mark.parametrize("cfg,n,t", [("dynerf_default", 2100, 0.37), ("hypernerf_default", 700, 1.0), ("dnerf_bouncingballs", 900, 0.0)])
+def test_deform_parity_one_frame_time(cfg, n, t):
+    """render() hands ONE frame time to all Gaussians: the plane-gradient kernel then privatises the three time planes in
+    LDS (csrc/deform.hip D4).  Same tight comparison as above, including t on the first/last time row (border clamp)."""
+    _parity(cfg, n, True, scalar_time=t)
+
+
+def _parity(cfg, n, activate, scalar_time=None):
     dev = torch.device("cuda:0")
     fd = _fdgs()
-    args, net, ins = _net_and_inputs(cfg, n, 3, dev)
+    args, net, ins = _net_and_inputs(cfg, n, 3, dev, fixed_time=scalar_time)
     # oracle on CPU with the same state dict
     sd = {k: v.detach().clone().contiguous().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
           for k, v in net.state_dict().items()}
@@ -64,7 +77,8 @@ def test_deform_forward_backward_parity(cfg, n, activate):
     ref = DO.deform_forward(sd, args, *cpu_in, activate=activate)
     net = net.to(dev)
     gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
-    out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=activate)
+    out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5] if scalar_time is None else float(scalar_time),
+                                activate=activate)
     torch.cuda.synchronize()
     names = ("xyz", "scales", "rot", "opacity", "shs")
     for k, a, b in zip(names, out, ref):

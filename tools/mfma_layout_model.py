@@ -1,0 +1,174 @@
+"""Lane-level numpy model of the MFMA register layouts used by csrc/deform.hip (development aid, CPU only).
+
+Mirrors the index arithmetic of DenseTrunk / DenseIL / DenseT / store_il / the dW2 and dh1 blocks with an exact model of
+v_mfma_f32_32x32x2_f32 (A[i][k] in lane i+32k, B[k][j] in lane j+32k, D[i][j] in lane j+32*hh register r with
+i = rho(r,hh)), and checks every product against plain matrix algebra.  Run: python tools/mfma_layout_model.py
+"""
+import numpy as np
+
+LANES = np.arange(64)
+G = LANES & 31
+H = LANES >> 5
+
+
+def rho(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def mfma32(a, b, c):
+    """a, b: [64]; c: [64,16] -> new c."""
+    A = np.stack([a[:32], a[32:]], 1)          # A[i][k]
+    B = np.stack([b[:32], b[32:]], 0)          # B[k][j]
+    D = A @ B                                  # [32 i][32 j]
+    out = c.copy()
+    for r in range(16):
+        for hh in range(2):
+            out[32 * hh:32 * hh + 32, r] += D[rho(r, hh), :]
+    return out
+
+
+def dense_trunk(W0, b0, feat, FCH, OT):
+    """feat[tile][lane, reg] chunk layout -> hid[ot][lane, reg] interleaved rows (row = OT*i + ot)."""
+    Y = [np.zeros((64, 16)) for _ in range(OT)]
+    for ot in range(OT):
+        for r in range(16):
+            Y[ot][:, r] = b0[OT * rho(r, H) + ot]
+    for j in range(FCH):
+        for c in range(4):
+            for ot in range(OT):
+                a = W0[OT * G + ot, 8 * j + 4 * H + c]
+                Y[ot] = mfma32(a, feat[j // 4][:, 4 * (j % 4) + c], Y[ot])
+    return Y
+
+
+def dense_il(Wm, bias, out_dim, X, KT, OT, row_il):
+    Y = [np.zeros((64, 16)) for _ in range(OT)]
+    for ot in range(OT):
+        for r in range(16):
+            row = OT * rho(r, H) + ot if row_il else 32 * ot + rho(r, H)
+            Y[ot][:, r] = bias[np.minimum(row, out_dim - 1)]
+    for s in range(16):
+        for t in range(KT):
+            for ot in range(OT):
+                row = OT * G + ot if row_il else 32 * ot + G
+                row = np.minimum(row, out_dim - 1)
+                a = Wm[row, KT * rho(s, 0) + KT * 4 * H + t]
+                Y[ot] = mfma32(a, X[t][:, s], Y[ot])
+    return Y
+
+
+def dense_T(Wm, in_valid, dY, YT, XT, col_il):
+    dX = [np.zeros((64, 16)) for _ in range(XT)]
+    for s in range(16 * YT):
+        r, t = s // YT, s % YT
+        wrow = YT * rho(r, 0) + t + YT * 4 * H
+        b = dY[t][:, r]
+        for xt in range(XT):
+            col = XT * G + xt if col_il else np.minimum(32 * xt + G, in_valid - 1)
+            dX[xt] = mfma32(Wm[wrow, col], b, dX[xt])
+    return dX
+
+
+def il_to_matrix(X, T):
+    """interleaved tiles -> [32 gaussians, 32*T features]."""
+    M = np.zeros((32, 32 * T))
+    for t in range(T):
+        for r in range(16):
+            for hh in range(2):
+                M[:, T * rho(r, hh) + t] = X[t][32 * hh:32 * hh + 32, r]
+    return M
+
+
+def tile_to_matrix(X, T):
+    """tile layout (row = 32*t + rho) -> [32 gaussians, 32*T]."""
+    M = np.zeros((32, 32 * T))
+    for t in range(T):
+        for r in range(16):
+            for hh in range(2):
+                M[:, 32 * t + rho(r, hh)] = X[t][32 * hh:32 * hh + 32, r]
+    return M
+
+
+def matrix_to_chunks(F, FCH):
+    """[32, 8*FCH] -> chunk-layout tiles."""
+    FT = (FCH + 3) // 4
+    X = [np.zeros((64, 16)) for _ in range(FT)]
+    for j in range(FCH):
+        for c in range(4):
+            X[j // 4][:, 4 * (j % 4) + c] = F[G, 8 * j + 4 * H + c]
+    return X
+
+
+def matrix_to_il(M, T):
+    X = [np.zeros((64, 16)) for _ in range(T)]
+    for t in range(T):
+        for r in range(16):
+            X[t][:, r] = M[G, T * rho(r, H) + t]
+    return X
+
+
+def check(WT, FCH, k, rng):
+    W, F = 32 * WT, 8 * FCH
+    feat = rng.standard_normal((32, F))
+    W0, b0 = rng.standard_normal((W, F)), rng.standard_normal(W)
+    W1, b1 = rng.standard_normal((W, W)), rng.standard_normal(W)
+    W2, b2 = rng.standard_normal((k, W)), rng.standard_normal(k)
+    hid_ref = np.maximum(feat @ W0.T + b0, 0)
+    h1_ref = np.maximum(hid_ref @ W1.T + b1, 0)
+    out_ref = h1_ref @ W2.T + b2
+    # forward chain
+    hid = dense_trunk(W0, b0, matrix_to_chunks(feat, FCH), FCH, WT)
+    hid = [np.maximum(x, 0) for x in hid]
+    assert np.allclose(il_to_matrix(hid, WT), hid_ref), "trunk"
+    h1 = [np.maximum(x, 0) for x in dense_il(W1, b1, W, hid, WT, WT, True)]
+    assert np.allclose(il_to_matrix(h1, WT), h1_ref), "L1"
+    nt2 = 2 if k > 32 else 1
+    outs = []
+    for ot2 in range(nt2):
+        kk = min(k - 32 * ot2, 32)
+        o = dense_il(W2[32 * ot2:], b2[32 * ot2:], kk, h1, WT, 1, False)
+        outs.append(tile_to_matrix(o, 1)[:, :kk])
+    assert np.allclose(np.concatenate(outs, 1), out_ref), "L2"
+    # backward: dh1 = G W2 (masked), dhid += dh1 W1, dfeat = dhid W0
+    Gm = rng.standard_normal((32, k))
+    dh1_ref = (Gm @ W2) * (h1_ref > 0)
+    dh1 = [np.zeros((64, 16)) for _ in range(WT)]
+    for s in range((k + 1) // 2):
+        o = 2 * s + H
+        a_rows = np.minimum(o, k - 1)
+        b = np.where(o < k, Gm[G, np.minimum(o, k - 1)], 0.0)
+        for t in range(WT):
+            dh1[t] = mfma32(W2[a_rows, WT * G + t], b, dh1[t])
+    dh1 = [x * (hh > 0) for x, hh in zip(dh1, h1)]
+    assert np.allclose(il_to_matrix(dh1, WT), dh1_ref), "dh1"
+    dhid = dense_T(W1, W, dh1, WT, WT, True)
+    dhid_ref = dh1_ref @ W1
+    assert np.allclose(il_to_matrix(dhid, WT), dhid_ref), "dhid"
+    FT = (FCH + 3) // 4
+    dfeat = dense_T(W0, F, dhid, WT, FT, False)
+    assert np.allclose(tile_to_matrix(dfeat, FT)[:, :F], dhid_ref @ W0), "dfeat"
+    # dW2 through the transposed LDS tile: lds[g][feature] = il_to_matrix(h1)
+    lds = il_to_matrix(h1, WT)
+    dW2 = np.zeros((k, W))
+    for ot2 in range(nt2):
+        o = 32 * ot2 + G
+        kk = k - 32 * ot2
+        for tb in range(WT):
+            acc = np.zeros((64, 16))
+            for s in range(16):
+                ga = np.where(o < k, Gm[2 * s + H, np.minimum(o, k - 1)], 0.0)
+                acc = mfma32(ga, lds[2 * s + H, tb * 32 + G], acc)
+            for r in range(16):
+                for lane in range(64):
+                    orow = rho(r, lane >> 5)
+                    if orow < kk:
+                        dW2[32 * ot2 + orow, tb * 32 + (lane & 31)] += acc[lane, r]
+    assert np.allclose(dW2, Gm.T @ h1_ref), "dW2"
+    return True
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for WT, FCH, k in [(4, 4, 3), (4, 4, 48), (4, 6, 4), (2, 8, 1), (2, 16, 48), (4, 12, 3)]:
+        check(WT, FCH, k, rng)
+        print(f"WT={WT} FCH={FCH} k={k}: layouts consistent")
