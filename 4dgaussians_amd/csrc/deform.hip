@@ -106,14 +106,18 @@ __device__ __forceinline__ void load_query(const fdgs_deform_params& p, int n, f
 }
 
 // features of lane (g,h): chunk j holds features 8j+4h .. +3 = registers 4(j%4)..+3 of tile j/4
-template <int FCH>
+// SERIAL: one chunk's 24 texel loads in flight at a time (256-register kernels: the scheduler otherwise hoists all
+// 24*FCH loads and spills their 96*FCH destination registers)
+template <int FCH, bool SERIAL = false>
 __device__ __forceinline__ void gather_features(const fdgs_deform_params& p, const float* q, int h, f32x16* feat) {
 #pragma unroll
     for (int j = 0; j < FCH; j++) {
+        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
         const float4 v = gather_chunk(p, 8 * j + 4 * h, q);
         feat[j / 4][4 * (j % 4) + 0] = v.x; feat[j / 4][4 * (j % 4) + 1] = v.y;
         feat[j / 4][4 * (j % 4) + 2] = v.z; feat[j / 4][4 * (j % 4) + 3] = v.w;
     }
+    if (SERIAL) __builtin_amdgcn_sched_barrier(0);
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA layers
@@ -309,8 +313,11 @@ __device__ __forceinline__ int next_head(const int* head_on, int hd) {
 template <int WT>
 struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
 
-template <int WT, int FCH>
-__global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
+// OCC = waves per SIMD the register budget is cut for: 1 (512 registers, deep prefetch) or 2 (256 registers, two waves
+// overlap each other's gather / epilogue phases)
+template <int WT, int FCH, int OCC>
+__global__ void __launch_bounds__(256, OCC) deform_fwd_kernel(DeformDev d) {
+    constexpr int PD1 = OCC == 1 ? FwdPD<WT>::L1 : (WT == 4 ? 1 : 2), PD2 = OCC == 1 ? FwdPD<WT>::L2 : 4;
     const fdgs_deform_params& p = d.p;
     constexpr int FT = (FCH + 3) / 4;
     const int lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
@@ -318,18 +325,21 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     const bool live = n_raw < p.N;
     const int n = live ? n_raw : p.N - 1;
     const int W = WT * 32;
-    DenseTrunk<FCH, WT, 2> T0;
-    T0.setup(p.w0, d.F, g, h);
-    T0.preload();
+    DenseTrunk<FCH, WT, OCC == 1 ? 2 : 1> T0;
+    if (OCC == 1) { T0.setup(p.w0, d.F, g, h); T0.preload(); }
     int hd = next_head(p.head_on, -1);
-    DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
-    if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
+    DenseIL<WT, WT, true, PD1, false> L1;
+    if (OCC == 1 && hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
     load_query(p, n, q, xyz);
     f32x16 feat[FT];
 #pragma unroll
     for (int t = 0; t < FT; t++) feat[t] = zero16();
-    gather_features<FCH>(p, q, h, feat);
+    gather_features<FCH, OCC != 1>(p, q, h, feat);
+    if (OCC != 1) {
+        T0.setup(p.w0, d.F, g, h); T0.preload();
+        if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
+    }
     f32x16 hid[WT];
     T0.run(p.b0, feat, hid, h);
     relu_inplace<WT>(hid);  // every consumer of the trunk output starts with ReLU (scene/deformation.py:61-65)
@@ -377,18 +387,20 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 
     while (hd < FDGS_NUM_HEADS) {
         const int k = head_k(hd);
-        DenseIL<WT, 1, false, FwdPD<WT>::L2> L2, L2b;
+        DenseIL<WT, 1, false, PD2> L2, L2b;
         L2.setup(p.w2[hd], W, k < 32 ? k : 32, g, h);
         L2.preload();
         f32x16 h1[WT];
         L1.run(p.b1[hd], W, hid, h1, h);
         relu_inplace<WT>(h1);
-        if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
+        if (OCC == 1 && k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head(p.head_on, hd);
-        if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
+        if (OCC == 1 && nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
         f32x16 o0, o1 = zero16();
         L2.run(p.b2[hd], k < 32 ? k : 32, h1, &o0, h);
+        if (OCC != 1 && k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
         if (k > 32) L2b.run(p.b2[hd] + 32, k - 32, h1, &o1, h);
+        if (OCC != 1 && nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
         if (hd == FDGS_HEAD_POS) {
             if (writer) {
                 d.out.xyz[3 * (size_t)n] = xyz[0] + o0[0]; d.out.xyz[3 * (size_t)n + 1] = xyz[1] + o0[1];
@@ -726,7 +738,7 @@ struct WgradArgs {
     WgradJob job[FDGS_NUM_HEADS + 1];
     int njobs, Npad, W;
 };
-constexpr int WG_PD = 3;
+constexpr int WG_PD = 6;
 
 // COLS_IL: X has exactly W columns, column mapping interleaved (vector loads); else tile mapping c = 32*b + j with
 // CT = ceil(ncols/32) dword loads per k-step (the small trunk product, ncols = C*L).
@@ -1019,7 +1031,8 @@ static int dispatch_wf(int W, int F, hipStream_t stream, int blocks, const Arg& 
 template <int WT, int FCH>
 struct FwdLauncher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
-        hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
+        if (tunable("FDGS_D1_OCC", 1) == 2) hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH, 2>), dim3(blocks), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH, 1>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
 template <int WT, int FCH>
@@ -1149,12 +1162,22 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int total_wgs = tunable("FDGS_WGRAD_WGS", cus);
         int work[FDGS_NUM_HEADS + 1], total_work = 0;
-        for (int j = 0; j < nj; j++) { work[j] = (wa.job[j].ncols + 31) / 32; total_work += work[j]; }
+        // cost model: MFMAs per k-step; the narrow trunk product (dword loads, only CT MFMAs per load pair) is
+        // load-latency bound, measured ~2.5x slower per MFMA than the square head products
+        const int trunk_factor = tunable("FDGS_WGRAD_TRUNK", 3);
+        for (int j = 0; j < nj; j++) {
+            work[j] = (wa.job[j].ncols + 31) / 32;
+            if (wa.job[j].ncols != (int)W) work[j] *= trunk_factor;
+            total_work += work[j];
+        }
+        // floor shares: never more workgroups than CUs (a single straggler would double the kernel time)
+        int nbs[FDGS_NUM_HEADS + 1], used = 0;
+        for (int j = 0; j < nj; j++) { nbs[j] = (int)((long long)total_wgs * work[j] / total_work); if (nbs[j] < 1) nbs[j] = 1; used += nbs[j]; }
+        for (int j = 0; used < total_wgs; j = (j + 1) % nj) { nbs[j]++; used++; }   // leftovers round-robin, heads first
         int first = 0;
         for (int j = 0; j < nj; j++) {
             WgradJob& J = wa.job[j];
-            int nb = (int)(((long long)total_wgs * work[j] + total_work / 2) / total_work);
-            if (nb < 1) nb = 1;
+            int nb = nbs[j];
             int chunk = (int)((Np + nb - 1) / nb);
             chunk = (chunk + 7) / 8 * 8;        // four waves x two Gaussians per MFMA k-step
             if (chunk < 64) chunk = 64;

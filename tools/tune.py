@@ -20,6 +20,10 @@ sys.path.insert(0, ROOT)
 
 SWEEPS = [
     ("default", {}),
+    ("wg_trunk=2", {"FDGS_WGRAD_TRUNK": "2"}),
+    ("wg_trunk=4", {"FDGS_WGRAD_TRUNK": "4"}),
+    ("wg_trunk=6", {"FDGS_WGRAD_TRUNK": "6"}),
+    ("d1_occ=2", {"FDGS_D1_OCC": "2"}),
     ("pg_lds=0", {"FDGS_PG_LDS": "0"}),
     ("pg_wgs=256", {"FDGS_PG_WGS": "256"}),
     ("pg_wgs=1024", {"FDGS_PG_WGS": "1024"}),
@@ -29,7 +33,7 @@ SWEEPS = [
     ("wgrad_wgs=128", {"FDGS_WGRAD_WGS": "128"}),
     ("wgrad_wgs=512", {"FDGS_WGRAD_WGS": "512"}),
 ]
-KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS")
+KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS", "FDGS_WGRAD_TRUNK", "FDGS_D1_OCC")
 
 
 def main():
