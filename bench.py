@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="cfg4_dynerf_300k_1352x1014", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=4)
     args = ap.parse_args()
 
     fdgs = importlib.import_module("4dgaussians_amd")
@@ -182,12 +182,15 @@ def main():
 def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
     """The same frame on the host cores: oracle deformation (torch CPU) -> oracle rasterizer (C, OpenMP), fwd + bwd.
     kind = "port": the rasterizer restatement is ours (the reference has no CPU rasterizer); the deformation oracle is
-    pinned to the reference's modules (tests/test_oracle_deform.py)."""
+    pinned to the reference's modules (tests/test_oracle_deform.py).  Bounded sample: `frames` full frame(s) of the bench
+    workload on min(cores, 64) threads (more threads only add scheduling overhead to these memory-bound loops)."""
     import numpy as np
     from oracle import deform_oracle as DO
-    from oracle.raster_oracle import RasterOracle
+    from oracle import raster_oracle as RO
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, int(os.environ.get("FDGS_CPU_THREADS", "64")))
+    torch.set_num_threads(threads)
+    RO.set_threads(threads)
     sd = {k: v.detach().cpu().contiguous().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
           for k, v in pc._deformation.state_dict().items()}
     leaves = {k: getattr(pc, k).detach().cpu().clone().requires_grad_(True)
@@ -196,27 +199,36 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
     cam = cam.to("cpu")
     tgt = target.cpu().numpy()
     n = leaves["_xyz"].shape[0]
+    stage = {"deform_fwd": 0.0, "raster_fwd": 0.0, "raster_bwd": 0.0, "deform_bwd": 0.0}
     t0 = time.perf_counter()
     for _ in range(frames):
+        ta = time.perf_counter()
         shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
         outs = DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
                                  torch.full((n, 1), cam.time), activate=True)
+        tb = time.perf_counter()
         f = lambda x: np.ascontiguousarray(x.detach().numpy())
-        o = RasterOracle(means3D=f(outs[0]), scales=f(outs[1]), rotations=f(outs[2]), opacities=f(outs[3]), shs=f(outs[4]),
-                         viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
-                         bg=np.zeros(3, np.float32), image_height=cam.image_height, image_width=cam.image_width,
-                         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+        o = RO.RasterOracle(means3D=f(outs[0]), scales=f(outs[1]), rotations=f(outs[2]), opacities=f(outs[3]), shs=f(outs[4]),
+                            viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
+                            bg=np.zeros(3, np.float32), image_height=cam.image_height, image_width=cam.image_width,
+                            tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+        tc = time.perf_counter()
         dc = (np.sign(o.color - tgt) / o.color.size).astype(np.float32)
         g = o.backward(dc)
+        td = time.perf_counter()
         gouts = [torch.tensor(g["means3D"]), torch.tensor(g["scales"]), torch.tensor(g["rotations"]),
                  torch.tensor(g["opacities"]).reshape(outs[3].shape), torch.tensor(g["shs"]).reshape(outs[4].shape)]
         torch.autograd.grad(list(outs), list(leaves.values()) + [v for v in sd.values() if v.requires_grad], grad_outputs=gouts,
                             allow_unused=True)
+        te = time.perf_counter()
         o.close()
+        for k_, v_ in zip(stage, (tb - ta, tc - tb, td - tc, te - td)):
+            stage[k_] += v_
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s of CPU time on {cores} threads; "
-                      "deformation = oracle pinned to the reference modules, rasterizer = our C restatement (OpenMP)"}
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s wall on {threads} threads of {cores} host cores; "
+                      "deformation = oracle pinned to the reference modules (torch CPU), rasterizer = our C restatement (OpenMP)",
+            "stage_seconds": {k_: round(v_, 3) for k_, v_ in stage.items()}}
 
 
 if __name__ == "__main__":

@@ -22,6 +22,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifdef ORACLE_DOUBLE
 typedef double REAL;
@@ -608,3 +611,14 @@ void oracle_raster_backward(void *h, const REAL *dL_dcolor, const REAL *dL_ddept
 }
 
 int oracle_real_size(void) { return (int)sizeof(REAL); }
+
+/* Number of OpenMP threads used by the parallel loops above (bench.py's cpu_baseline states the count it used). */
+int oracle_raster_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

@@ -43,8 +43,15 @@ def _lib(dtype):
         lib.oracle_raster_field.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.oracle_raster_num_rendered.argtypes = [ctypes.c_void_p]
         lib.oracle_raster_free.argtypes = [ctypes.c_void_p]
+        lib.oracle_raster_set_threads.argtypes = [ctypes.c_int]
+        lib.oracle_raster_set_threads.restype = ctypes.c_int
         _LIBS[name] = lib
     return _LIBS[name]
+
+
+def set_threads(n, dtype=np.float32):
+    """OpenMP thread count of the C restatement; returns the count in effect."""
+    return int(_lib(dtype).oracle_raster_set_threads(int(n)))
 
 
 def _ptr(a):
