@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         stale = force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, *FLAGS, *os.environ.get("FDGS_EXTRA_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

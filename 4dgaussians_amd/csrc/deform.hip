@@ -22,12 +22,19 @@
 //      (scattered float atomics run at only ~20 G line-ops/s on MI355X: profiles/r01_atomic_microbench.txt).
 #include "common.h"
 
+#include <vector>
+
 namespace fdgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16 independent 4x4x1 outer products: lane 4b+i holds A_b[i], lane 4b+j holds B_b[j], lane 4b+j register i gets D_b[i][j]
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -72,6 +79,7 @@ struct DeformDev {
     fdgs_deform_params p;
     fdgs_deform_out out;
     int F;
+    int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
 };
 
 // 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian
@@ -106,18 +114,14 @@ __device__ __forceinline__ void load_query(const fdgs_deform_params& p, int n, f
 }
 
 // features of lane (g,h): chunk j holds features 8j+4h .. +3 = registers 4(j%4)..+3 of tile j/4
-// SERIAL: one chunk's 24 texel loads in flight at a time (256-register kernels: the scheduler otherwise hoists all
-// 24*FCH loads and spills their 96*FCH destination registers)
-template <int FCH, bool SERIAL = false>
+template <int FCH>
 __device__ __forceinline__ void gather_features(const fdgs_deform_params& p, const float* q, int h, f32x16* feat) {
 #pragma unroll
     for (int j = 0; j < FCH; j++) {
-        if (SERIAL) __builtin_amdgcn_sched_barrier(0);
         const float4 v = gather_chunk(p, 8 * j + 4 * h, q);
         feat[j / 4][4 * (j % 4) + 0] = v.x; feat[j / 4][4 * (j % 4) + 1] = v.y;
         feat[j / 4][4 * (j % 4) + 2] = v.z; feat[j / 4][4 * (j % 4) + 3] = v.w;
     }
-    if (SERIAL) __builtin_amdgcn_sched_barrier(0);
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA layers
@@ -156,13 +160,18 @@ __device__ __forceinline__ AVec<VW> ldv(const float* __restrict__ p) {
 template <int KT, int OT, bool ROW_IL, int PD, bool CLAMP = true>
 struct DenseIL {
     const float* rp[OT];
+    const float* bp[OT];
+    float bv[OT];
     AVec<KT> buf[PD][OT];
-    __device__ __forceinline__ void setup(const float* __restrict__ Wm, int ld, int out_dim, int g, int h) {
+    // The bias enters as one extra MFMA k-step (A = bias[row] in the k = 0 half, 0 in the k = 1 half; B = 1): its four
+    // dword loads ride with the weight prefetch instead of stalling the first MFMA of the layer on 64 bias loads.
+    __device__ __forceinline__ void setup(const float* __restrict__ Wm, const float* __restrict__ bias, int ld, int out_dim, int g, int h) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
             int row = ROW_IL ? OT * g + ot : 32 * ot + g;
             if (CLAMP) row = row < out_dim ? row : out_dim - 1;
             rp[ot] = Wm + (size_t)row * ld + KT * 4 * h;
+            bp[ot] = bias + row;
         }
     }
     __device__ __forceinline__ void fetch(int s, AVec<KT>* dst) const {
@@ -171,18 +180,50 @@ struct DenseIL {
     }
     __device__ __forceinline__ void preload() {
 #pragma unroll
+        for (int ot = 0; ot < OT; ot++) bv[ot] = *bp[ot];
+#pragma unroll
         for (int s = 0; s < PD; s++) fetch(s, buf[s]);
     }
-    __device__ __forceinline__ void run(const float* __restrict__ bias, int out_dim, const f32x16* X, f32x16* Y, int h) {
+    // ---- k <= 4 output rows (position / scale / rotation / opacity heads): instead of padding the 3..4 rows to a 32-row
+    // MFMA tile (64 MFMAs of 64 cycles at 9-12 % use) the product runs on v_mfma_f32_4x4x1_16b: block b = lane/4 holds
+    // four Gaussians (B = the interleaved activation register as it is), A-lane 4b+i = W[i][feature of this half];
+    // 64 instructions of 8 cycles.  The two lane halves hold partial sums over their halves of the features.
+    __device__ __forceinline__ void setup4(const float* __restrict__ Wm, const float* __restrict__ bias, int ld, int out_dim, int g, int h) {
+        static_assert(OT == 1, "small-output form has one output tile");
+        int row = g & 3;
+        row = row < out_dim ? row : out_dim - 1;
+        rp[0] = Wm + (size_t)row * ld + KT * 4 * h;
+        bp[0] = bias + row;
+    }
+    // returns out[i] (i < 4) of the lane's Gaussian in .x .y .z .w, valid in every lane
+    __device__ __forceinline__ f32x4 run4(const f32x16* X) {
+        f32x4 acc[KT];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int t = 0; t < KT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ot = 0; ot < OT; ot++) {
-                int row = ROW_IL ? OT * rho(r, h) + ot : 32 * ot + rho(r, h);
-                if (CLAMP) row = row < out_dim ? row : out_dim - 1;
-                Y[ot][r] = bias[row];
-            }
+        for (int s = 0; s < 16; s++) {
+            const AVec<KT> cur = buf[s % PD][0];
+            if (s + PD < 16) fetch(s + PD, buf[s % PD]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < KT; t++) acc[t] = mfma4(cur.v[t], X[t][s], acc[t]);
         }
+        f32x4 sum = acc[0];
+#pragma unroll
+        for (int t = 1; t < KT; t++) sum += acc[t];
+        // lane 4b+j register i = partial out[i] of Gaussian (4b+j)&31 over this half's features; bias of row i sits in the
+        // lanes with (lane & 3) == i
+        f32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float tot = sum[i] + __shfl_xor(sum[i], 32, 64);
+            out[i] = tot + __shfl(bv[0], i, 4);
+        }
+        return out;
+    }
+    __device__ __forceinline__ void run(const f32x16* X, f32x16* Y, int h) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(h == 0 ? bv[ot] : 0.f, 1.0f, zero16());
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             AVec<KT> cur[OT];
@@ -202,10 +243,13 @@ struct DenseIL {
 template <int FCH, int OT, int PD>
 struct DenseTrunk {
     const float* rp[OT];
+    const float* bp;
+    float bv[OT];
     float4 buf[PD][OT];
-    __device__ __forceinline__ void setup(const float* __restrict__ Wm, int ld, int g, int h) {
+    __device__ __forceinline__ void setup(const float* __restrict__ Wm, const float* __restrict__ bias, int ld, int g, int h) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) rp[ot] = Wm + (size_t)(OT * g + ot) * ld + 4 * h;
+        bp = bias + OT * g;
     }
     __device__ __forceinline__ void fetch(int j, float4* dst) const {
 #pragma unroll
@@ -213,13 +257,13 @@ struct DenseTrunk {
     }
     __device__ __forceinline__ void preload() {
 #pragma unroll
+        for (int ot = 0; ot < OT; ot++) bv[ot] = bp[ot];
+#pragma unroll
         for (int s = 0; s < PD; s++) if (s < FCH) fetch(s, buf[s]);
     }
-    __device__ __forceinline__ void run(const float* __restrict__ bias, const f32x16* feat, f32x16* Y, int h) {
+    __device__ __forceinline__ void run(const f32x16* feat, f32x16* Y, int h) {
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-#pragma unroll
-            for (int ot = 0; ot < OT; ot++) Y[ot][r] = bias[OT * rho(r, h) + ot];
+        for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(h == 0 ? bv[ot] : 0.f, 1.0f, zero16());
 #pragma unroll
         for (int j = 0; j < FCH; j++) {
             float4 cur[OT];
@@ -313,111 +357,69 @@ __device__ __forceinline__ int next_head(const int* head_on, int hd) {
 template <int WT>
 struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
 
-// OCC = waves per SIMD the register budget is cut for: 1 (512 registers, deep prefetch) or 2 (256 registers, two waves
-// overlap each other's gather / epilogue phases)
-template <int WT, int FCH, int OCC>
-__global__ void __launch_bounds__(256, OCC) deform_fwd_kernel(DeformDev d) {
-    constexpr int PD1 = OCC == 1 ? FwdPD<WT>::L1 : (WT == 4 ? 1 : 2), PD2 = OCC == 1 ? FwdPD<WT>::L2 : 4;
+template <int WT, int FCH>
+__global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
+    constexpr int PD1 = FwdPD<WT>::L1, PD2 = FwdPD<WT>::L2;
     const fdgs_deform_params& p = d.p;
+    const bool tunable_small = d.small_heads != 0;
     constexpr int FT = (FCH + 3) / 4;
     const int lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
     const int n_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + g;
     const bool live = n_raw < p.N;
     const int n = live ? n_raw : p.N - 1;
     const int W = WT * 32;
-    DenseTrunk<FCH, WT, OCC == 1 ? 2 : 1> T0;
-    if (OCC == 1) { T0.setup(p.w0, d.F, g, h); T0.preload(); }
+    DenseTrunk<FCH, WT, 2> T0;
+    T0.setup(p.w0, p.b0, d.F, g, h);
+    T0.preload();
     int hd = next_head(p.head_on, -1);
     DenseIL<WT, WT, true, PD1, false> L1;
-    if (OCC == 1 && hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
+    if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
     load_query(p, n, q, xyz);
+    // every per-Gaussian input of the epilogues is fetched now (one HBM round trip under the gather) instead of once per
+    // head behind its last MFMA
+    float in_sc[3], in_op, in_sh[24];
+#pragma unroll
+    for (int i = 0; i < 3; i++) in_sc[i] = p.scales[3 * (size_t)n + i];
+    const float4 in_rot = reinterpret_cast<const float4*>(p.rotations)[n];
+    in_op = p.opacity[n];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+        const int row0 = (u < 4 ? 0 : 32) + 8 * (u & 3) + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = row0 + i;
+            in_sh[4 * u + i] = m < 3 ? p.shs_dc[(size_t)p.shs_dc_stride * n + m] : p.shs_rest[(size_t)p.shs_rest_stride * n + (m - 3)];
+        }
+    }
     f32x16 feat[FT];
 #pragma unroll
     for (int t = 0; t < FT; t++) feat[t] = zero16();
-    gather_features<FCH, OCC != 1>(p, q, h, feat);
-    if (OCC != 1) {
-        T0.setup(p.w0, d.F, g, h); T0.preload();
-        if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
-    }
+    gather_features<FCH>(p, q, h, feat);
     f32x16 hid[WT];
-    T0.run(p.b0, feat, hid, h);
+    T0.run(feat, hid, h);
     relu_inplace<WT>(hid);  // every consumer of the trunk output starts with ReLU (scene/deformation.py:61-65)
 
     const bool writer = live && h == 0;
-    // heads that are switched off return their input unchanged (scene/deformation.py:106-146)
-    if (!p.head_on[FDGS_HEAD_POS] && writer) {
-        d.out.xyz[3 * (size_t)n] = xyz[0]; d.out.xyz[3 * (size_t)n + 1] = xyz[1]; d.out.xyz[3 * (size_t)n + 2] = xyz[2];
-    }
-    if (!p.head_on[FDGS_HEAD_SCALE] && writer) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const float v = p.scales[3 * (size_t)n + i];
-            d.out.scales[3 * (size_t)n + i] = p.activate ? __expf(v) : v;
-        }
-    }
-    if (!p.head_on[FDGS_HEAD_ROT] && writer) {
-        const float4 r = reinterpret_cast<const float4*>(p.rotations)[n];
-        float v0 = r.x, v1 = r.y, v2 = r.z, v3 = r.w;
-        if (p.activate) {
-            const float nrm = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3);
-            const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-            v0 *= inv; v1 *= inv; v2 *= inv; v3 *= inv;
-            if (d.out.rot_norm) d.out.rot_norm[n] = nrm;
-        }
-        reinterpret_cast<float4*>(d.out.rotations)[n] = make_float4(v0, v1, v2, v3);
-    }
-    if (!p.head_on[FDGS_HEAD_OPACITY] && writer) {
-        const float v = p.opacity[n];
-        d.out.opacity[n] = p.activate ? sigmoidf_(v) : v;
-    }
-    if (!p.head_on[FDGS_HEAD_SHS] && live) {
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int row0 = (u < 4 ? 0 : 32) + 8 * (u & 3) + 4 * h;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int m = row0 + i;
-                v[i] = m < 3 ? p.shs_dc[(size_t)p.shs_dc_stride * n + m] : p.shs_rest[(size_t)p.shs_rest_stride * n + (m - 3)];
-            }
-            *reinterpret_cast<float4*>(d.out.shs + 48 * (size_t)n + row0) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-
-    while (hd < FDGS_NUM_HEADS) {
-        const int k = head_k(hd);
-        DenseIL<WT, 1, false, PD2> L2, L2b;
-        L2.setup(p.w2[hd], W, k < 32 ? k : 32, g, h);
-        L2.preload();
-        f32x16 h1[WT];
-        L1.run(p.b1[hd], W, hid, h1, h);
-        relu_inplace<WT>(h1);
-        if (OCC == 1 && k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
-        const int nxt = next_head(p.head_on, hd);
-        if (OCC == 1 && nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
-        f32x16 o0, o1 = zero16();
-        L2.run(p.b2[hd], k < 32 ? k : 32, h1, &o0, h);
-        if (OCC != 1 && k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, W, k - 32, g, h); L2b.preload(); }
-        if (k > 32) L2b.run(p.b2[hd] + 32, k - 32, h1, &o1, h);
-        if (OCC != 1 && nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], W, W, g, h); L1.preload(); }
-        if (hd == FDGS_HEAD_POS) {
+    // epilogue of head hd applied to the head's output delta (zero for a switched-off head: it returns its input
+    // unchanged, scene/deformation.py:106-146)
+    auto epilogue = [&](int hd_, const f32x16& o0, const f32x16& o1) {
+        if (hd_ == FDGS_HEAD_POS) {
             if (writer) {
                 d.out.xyz[3 * (size_t)n] = xyz[0] + o0[0]; d.out.xyz[3 * (size_t)n + 1] = xyz[1] + o0[1];
                 d.out.xyz[3 * (size_t)n + 2] = xyz[2] + o0[2];
             }
-        } else if (hd == FDGS_HEAD_SCALE) {
+        } else if (hd_ == FDGS_HEAD_SCALE) {
             if (writer) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    float v = p.scales[3 * (size_t)n + i] + o0[i];
+                    const float v = in_sc[i] + o0[i];
                     d.out.scales[3 * (size_t)n + i] = p.activate ? __expf(v) : v;
                 }
             }
-        } else if (hd == FDGS_HEAD_ROT) {
+        } else if (hd_ == FDGS_HEAD_ROT) {
             if (writer) {
-                const float4 r = reinterpret_cast<const float4*>(p.rotations)[n];
-                float v0 = r.x + o0[0], v1 = r.y + o0[1], v2 = r.z + o0[2], v3 = r.w + o0[3];
+                float v0 = in_rot.x + o0[0], v1 = in_rot.y + o0[1], v2 = in_rot.z + o0[2], v3 = in_rot.w + o0[3];
                 if (p.activate) {
                     const float nrm = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3);
                     const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // F.normalize eps (scene/gaussian_model.py:44)
@@ -426,9 +428,9 @@ __global__ void __launch_bounds__(256, OCC) deform_fwd_kernel(DeformDev d) {
                 }
                 reinterpret_cast<float4*>(d.out.rotations)[n] = make_float4(v0, v1, v2, v3);
             }
-        } else if (hd == FDGS_HEAD_OPACITY) {
+        } else if (hd_ == FDGS_HEAD_OPACITY) {
             if (writer) {
-                const float v = p.opacity[n] + o0[0];
+                const float v = in_op + o0[0];
                 d.out.opacity[n] = p.activate ? sigmoidf_(v) : v;
             }
         } else {
@@ -439,15 +441,40 @@ __global__ void __launch_bounds__(256, OCC) deform_fwd_kernel(DeformDev d) {
                     const int row0 = (u < 4 ? 0 : 32) + 8 * (u & 3) + 4 * h;
                     float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int m = row0 + i;
-                        const float base = m < 3 ? p.shs_dc[(size_t)p.shs_dc_stride * n + m] : p.shs_rest[(size_t)p.shs_rest_stride * n + (m - 3)];
-                        v[i] = base + (u < 4 ? o0[4 * (u & 3) + i] : o1[4 * (u & 3) + i]);
-                    }
+                    for (int i = 0; i < 4; i++) v[i] = in_sh[4 * u + i] + (u < 4 ? o0[4 * (u & 3) + i] : o1[4 * (u & 3) + i]);
                     *reinterpret_cast<float4*>(d.out.shs + 48 * (size_t)n + row0) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
+    };
+    {
+        const f32x16 z = zero16();
+        for (int h0 = 0; h0 < FDGS_NUM_HEADS; h0++)
+            if (!p.head_on[h0]) epilogue(h0, z, z);
+    }
+
+    while (hd < FDGS_NUM_HEADS) {
+        const int k = head_k(hd);
+        DenseIL<WT, 1, false, PD2> L2, L2b;
+        const bool small = k <= 4 && tunable_small;
+        if (small) L2.setup4(p.w2[hd], p.b2[hd], W, k, g, h);
+        else L2.setup(p.w2[hd], p.b2[hd], W, k < 32 ? k : 32, g, h);
+        L2.preload();
+        f32x16 h1[WT];
+        L1.run(hid, h1, h);
+        relu_inplace<WT>(h1);
+        if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, g, h); L2b.preload(); }
+        const int nxt = next_head(p.head_on, hd);
+        if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
+        f32x16 o0 = zero16(), o1 = zero16();
+        if (small) {
+            const f32x4 o4 = L2.run4(h1);
+            o0[0] = o4[0]; o0[1] = o4[1]; o0[2] = o4[2]; o0[3] = o4[3];
+        } else {
+            L2.run(h1, &o0, h);
+        }
+        if (k > 32) L2b.run(h1, &o1, h);
+        epilogue(hd, o0, o1);
         hd = nxt;
     }
 }
@@ -536,7 +563,13 @@ struct BwdDev {
     int F;
     int head_slot[FDGS_NUM_HEADS];  // index of the head's dH1 slab
     int ntiles;                     // 32-Gaussian tiles (Npad / 32)
+    unsigned long long* prof;       // development builds (-DFDGS_PROFILE_D2): per-wave cycle sums per phase
 };
+#ifdef FDGS_PROFILE_D2
+#define D2_TICK(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } while (0)
+#else
+#define D2_TICK(ph) do { } while (0)
+#endif
 
 // LDS of the backward kernel: per-wave transposed relu(h1) tile [32 gaussians][W + 4] (padded: conflict-free
 // ds_write_b128 / ds_read_b32) + workgroup accumulators of dW2 / db2 for all five heads (59 rows), flushed to global
@@ -567,6 +600,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     __syncthreads();
     const int F = d.F;
 
+#ifdef FDGS_PROFILE_D2
+    unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_t0 = prof_t;
+#endif
     for (int tile = blockIdx.x * 4 + wave; tile < d.ntiles; tile += gridDim.x * 4) {
         // opaque per-iteration copies of the lane coordinates: keeps the (hundreds of) loop-invariant weight addresses
         // from being hoisted out of the tile loop and held in registers across it
@@ -576,11 +614,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         const int n_row = n0 + g;
         const int n = n_row < p.N ? n_row : p.N - 1;
         DenseTrunk<FCH, WT, 2> T0;
-        T0.setup(p.w0, F, g, h);
+        T0.setup(p.w0, p.b0, F, g, h);
         T0.preload();
         int hd = next_head(p.head_on, -1);
         DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
-        L1.setup(p.w1[hd], W, W, g, h);   // at least one head is active (checked on the host)
+        L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);   // at least one head is active (checked on the host)
         L1.preload();
         float q[4], xyz[3];
         load_query(p, n, q, xyz);
@@ -593,9 +631,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             *reinterpret_cast<float4*>(d.s.FEAT + (size_t)n_row * F + 8 * j + 4 * h) =
                 make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
         f32x16 hid[WT], dhid[WT];
-        T0.run(p.b0, feat, hid, h);
+        D2_TICK(0);
+        T0.run(feat, hid, h);
         relu_inplace<WT>(hid);
         store_il<WT>(d.s.RH + (size_t)n_row * W, hid, h);
+        D2_TICK(1);
 #pragma unroll
         for (int t = 0; t < WT; t++) dhid[t] = zero16();
         const float* Grow = d.s.G + (size_t)n_row * GCOLS;
@@ -605,9 +645,22 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             const int k = head_k(hd), off = head_off(hd), row0 = head_row0(hd);
             uint32_t mask[WT];  // bit r of mask[t]: h1[t][r] > 0
             const int nt2 = k > 32 ? 2 : 1;
+            // operands that depend on nothing computed in this head are requested first: the head's packed output-gradient
+            // rows for the dW2 product (A-lane: output o = 32*ot2 + g, gaussian 2s+h) ...
+            // (loads are unconditional -- columns past the head's k outputs lie inside the scratch buffer -- and zeroed by
+            // a select: a conditional load becomes a branch that the compiler sinks to the use, exposing its latency)
+            float ga[16];
+            {
+                const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + g;
+#pragma unroll
+                for (int s = 0; s < 16; s++) ga[s] = gp[(size_t)2 * s * GCOLS];
+#pragma unroll
+                for (int s = 0; s < 16; s++) ga[s] = g < k ? ga[s] : 0.f;
+            }
             {
                 f32x16 h1[WT];
-                L1.run(p.b1[hd], W, hid, h1, h);
+                L1.run(hid, h1, h);
+                D2_TICK(2);
 #pragma unroll
                 for (int t = 0; t < WT; t++) {
                     mask[t] = 0;
@@ -620,25 +673,38 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 // transposed copy relu(h1)[gaussian][feature] for the dW2 product
                 store_il<WT>(lds + g * STRIDE, h1, h);
             }
-            // first operands of the long transposed product in flight before the dW2 block
+            // ... the first operands of the long transposed product, and of dh1 = W2^T G_head (k-steps over the head's
+            // outputs, two per MFMA: A = W2 row o, B = G[gaussian][o])
             DenseT<WT, WT, true, 4> B1;
             B1.setup(p.w1[hd], W, W, g, h);
             B1.preload();
+            const float* w2p = p.w2[hd] + WT * g;
+            const int nsteps = (k + 1) >> 1;
+            auto ldA = [&](int s) { int o = 2 * s + h; o = o < k ? o : k - 1; return ldv<WT>(w2p + (size_t)o * W); };
+            auto ldB = [&](int s) { const int o = 2 * s + h; const float v = Grow[off + o]; return o < k ? v : 0.f; };
+            AVec<WT> a0 = ldA(0), a1 = ldA(1 < nsteps ? 1 : 0), a2 = ldA(2 < nsteps ? 2 : 0);
+            float b0 = ldB(0), b1 = 1 < nsteps ? ldB(1) : 0.f, b2 = 2 < nsteps ? ldB(2) : 0.f;
+            __builtin_amdgcn_sched_barrier(0);   // keep these requests ahead of the dW2 block
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            D2_TICK(3);
             // ---- dW2[o][in] += sum_g G[g][o] * relu(h1)[g][in];  db2[o] += sum_g G[g][o]
             for (int ot2 = 0; ot2 < nt2; ot2++) {
-                // A-lane (o = 32*ot2 + g, gaussian 2s+h): the head's packed output-gradient rows
                 const int o = ot2 * 32 + g;
-                float ga[16];
+                if (ot2 > 0) {
+                    const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + o;
 #pragma unroll
-                for (int s = 0; s < 16; s++) ga[s] = o < k ? d.s.G[(size_t)(n0 + 2 * s + h) * GCOLS + off + o] : 0.f;
+                    for (int s = 0; s < 16; s++) ga[s] = gp[(size_t)2 * s * GCOLS];
+#pragma unroll
+                    for (int s = 0; s < 16; s++) ga[s] = o < k ? ga[s] : 0.f;
+                }
                 float asum = 0.f;
 #pragma unroll
                 for (int s = 0; s < 16; s++) asum += ga[s];
                 asum += __shfl_xor(asum, 32, 64);
                 const int kk = k - ot2 * 32;  // valid rows of this 32-row output tile
                 if (h == 0 && g < kk) atomicAdd(&accB2[row0 + ot2 * 32 + g], asum);
+                D2_TICK(10);
 #pragma unroll
                 for (int tb = 0; tb < WT; tb += 2) {   // two feature tiles at a time: 32 accumulator registers
                     f32x16 acc0 = zero16(), acc1 = zero16();
@@ -647,6 +713,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                         acc0 = mfma32(ga[s], lds[(2 * s + h) * STRIDE + tb * 32 + g], acc0);
                         acc1 = mfma32(ga[s], lds[(2 * s + h) * STRIDE + (tb + 1) * 32 + g], acc1);
                     }
+                    D2_TICK(11);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int orow = rho(r, h);
@@ -657,37 +724,33 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                     }
                 }
             }
-            // ---- dh1 = W2^T G_head (k-steps over the head's outputs, two per MFMA), masked by relu'(h1)
+            D2_TICK(4);
+            // ---- dh1 = W2^T G_head, masked by relu'(h1)
             f32x16 dh1[WT];
 #pragma unroll
             for (int t = 0; t < WT; t++) dh1[t] = zero16();
-            {
-                const float* w2p = p.w2[hd] + WT * g;
-                const int nsteps = (k + 1) >> 1;
-                auto ldA = [&](int s) { int o = 2 * s + h; o = o < k ? o : k - 1; return ldv<WT>(w2p + (size_t)o * W); };
-                auto ldB = [&](int s) { const int o = 2 * s + h; return o < k ? Grow[off + o] : 0.f; };
-                AVec<WT> a0 = ldA(0), a1 = ldA(1 < nsteps ? 1 : 0), a2 = ldA(2 < nsteps ? 2 : 0);
-                float b0 = ldB(0), b1 = 1 < nsteps ? ldB(1) : 0.f, b2 = 2 < nsteps ? ldB(2) : 0.f;
-                for (int s = 0; s < nsteps; s++) {
-                    const AVec<WT> a = a0;
-                    const float b = b0;
-                    a0 = a1; b0 = b1; a1 = a2; b1 = b2;
-                    if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
+            for (int s = 0; s < nsteps; s++) {
+                const AVec<WT> a = a0;
+                const float b = b0;
+                a0 = a1; b0 = b1; a1 = a2; b1 = b2;
+                if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
 #pragma unroll
-                    for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
-                }
+                for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
             }
+            D2_TICK(5);
             float* slab = d.s.DH1 + (size_t)d.head_slot[hd] * d.s.Npad * W;
 #pragma unroll
             for (int t = 0; t < WT; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) dh1[t][r] = ((mask[t] >> r) & 1u) ? dh1[t][r] : 0.f;
             store_il<WT>(slab + (size_t)n_row * W, dh1, h);
+            D2_TICK(6);
             // ---- dhid += W1^T dh1
             B1.run(dh1, dhid);
             __builtin_amdgcn_wave_barrier();
+            D2_TICK(7);
             hd = next_head(p.head_on, hd);
-            if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], W, W, g, h); L1.preload(); }
+            if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
         }
         // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
         DenseT<WT, FT, false, 4> B0;
@@ -707,7 +770,16 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             *reinterpret_cast<float4*>(d.s.DFEAT + (size_t)n_row * F + 8 * j + 4 * h) =
                 make_float4(dfeat[j / 4][4 * (j % 4)], dfeat[j / 4][4 * (j % 4) + 1], dfeat[j / 4][4 * (j % 4) + 2],
                             dfeat[j / 4][4 * (j % 4) + 3]);
+        D2_TICK(8);
     }
+#ifdef FDGS_PROFILE_D2
+    if (d.prof && lane == 0) {
+        unsigned long long* out = d.prof + (size_t)(blockIdx.x * 4 + wave) * 12;
+        for (int i = 0; i < 9; i++) out[i] = prof_acc[i];
+        out[9] = __builtin_amdgcn_s_memtime() - prof_t0;
+        out[10] = prof_acc[10]; out[11] = prof_acc[11];
+    }
+#endif
     // flush the workgroup's dW2 / db2 sums
     __syncthreads();
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
@@ -1031,8 +1103,7 @@ static int dispatch_wf(int W, int F, hipStream_t stream, int blocks, const Arg& 
 template <int WT, int FCH>
 struct FwdLauncher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
-        if (tunable("FDGS_D1_OCC", 1) == 2) hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH, 2>), dim3(blocks), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH, 1>), dim3(blocks), dim3(256), 0, s, d);
+        hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
 template <int WT, int FCH>
@@ -1073,7 +1144,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     if (p->N == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeformDev d;
-    d.p = *p; d.out = *out; d.F = p->C * p->L;
+    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1);
     {
         FDGS_TIMED("deform_fwd", stream);
         rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, cdiv(p->N, 128), d);
@@ -1134,10 +1205,38 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         bd.d_w2[hd] = g->d_w2[hd]; bd.d_b2[hd] = g->d_b2[hd];
         bd.head_slot[hd] = p->head_on[hd] ? slot++ : 0;
     }
+    bd.prof = nullptr;
+#ifdef FDGS_PROFILE_D2
+    static unsigned long long* prof_dev = nullptr;
+    const size_t prof_n = 4096 * 12;
+    if (!prof_dev) (void)hipMalloc(&prof_dev, prof_n * sizeof(unsigned long long));
+    (void)hipMemsetAsync(prof_dev, 0, prof_n * sizeof(unsigned long long), stream);
+    bd.prof = prof_dev;
+#endif
     {
         FDGS_TIMED("deform_bwd_data", stream);
         rc = dispatch_wf<BwdLauncher>(p->W, (int)F, stream, (int)(Np / 128), bd);
     }
+#ifdef FDGS_PROFILE_D2
+    {
+        static int reports = 0;
+        if (reports++ == 5) {   // one report, after warm-up
+            std::vector<unsigned long long> hbuf(prof_n);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(hbuf.data(), prof_dev, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double sum[12] = {0}; int waves = 0;
+            for (size_t w = 0; w < 4096; w++) {
+                if (hbuf[w * 12 + 9] == 0) continue;
+                waves++;
+                for (int i = 0; i < 12; i++) sum[i] += (double)hbuf[w * 12 + i];
+            }
+            const char* names[12] = {"gather+FEAT", "trunk+RH", "L1.run", "relu/mask/LDS+preloads", "dW2 flush", "dh1", "mask+DH1 store",
+                                     "B1.run", "tail(DHID,B0,DFEAT)", "wave total", "dW2 ga+asum", "dW2 mfma"};
+            fprintf(stderr, "[D2 profile] %d waves, s_memtime ticks (100 MHz) per wave:\n", waves);
+            for (int i = 0; i < 12; i++) fprintf(stderr, "  %-26s %12.0f  (%.1f %%)\n", names[i], sum[i] / waves, 100.0 * sum[i] / sum[9]);
+        }
+    }
+#endif
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_bwd_data", 0, stream);
     // weight gradients: one job per active head (dW1, db1) + the trunk (dW0, db0)

@@ -102,6 +102,15 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (= one 16-pixel line of the tile); every lane of the row ends with the row total
+__device__ __forceinline__ float row_allsum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  : xor 1
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  : xor 2
+    v += dpp_f<0x141>(v);  // row_half_mirror      : other quad of the 8
+    v += dpp_f<0x140>(v);  // row_mirror           : other half of the 16
+    return v;
+}
+
 struct RenderBwdArgs {
     int W, H, gx, gy;
     const uint2* ranges; const uint32_t* pair_gid;
@@ -174,7 +183,11 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
                   g_d = 0.f;
             if (valid) {
                 const float4 Cc = sC[j];
-                T = T / (1.0f - alpha);
+                // 1/(1-alpha) once (v_rcp_f32 + one Newton step, <= 1 ulp) for both divisions of the reference formula
+                const float om = 1.0f - alpha;
+                float inv = __builtin_amdgcn_rcpf(om);
+                inv = fmaf(fmaf(-om, inv, 1.0f), inv, inv);
+                T = T * inv;
                 const float w = alpha * T;
                 float dL_dalpha;
                 acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = Cc.x;
@@ -185,7 +198,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
                 g_c0 = w * dp0; g_c1 = w * dp1; g_c2 = w * dp2; g_d = w * ddep;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
+                dL_dalpha += (-T_final * inv) * bgdot;
                 const float dL_dG = B.y * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 const float dG_ddelx = -gdx * A.z - gdy * A.w;
@@ -194,16 +207,20 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
                 g_cxx = -0.5f * gdx * dx * dL_dG; g_cxy = -0.5f * gdx * dy * dL_dG; g_cyy = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            g_mx = wave_allsum(g_mx); g_my = wave_allsum(g_my);
-            g_cxx = wave_allsum(g_cxx); g_cxy = wave_allsum(g_cxy); g_cyy = wave_allsum(g_cyy);
-            g_op = wave_allsum(g_op);
-            g_c0 = wave_allsum(g_c0); g_c1 = wave_allsum(g_c1); g_c2 = wave_allsum(g_c2);
-            g_d = wave_allsum(g_d);
+            // per-Gaussian sums over the wave's 64 pixels: DPP butterflies inside each 16-lane row (4 instructions per
+            // value), then lanes 0..9 of EVERY row add "their" value into the LDS slot -- the four rows meet in the LDS
+            // atomic unit instead of in two more permlane swap stages per value (120 -> 50 VALU instructions per hit)
+            g_mx = row_allsum(g_mx); g_my = row_allsum(g_my);
+            g_cxx = row_allsum(g_cxx); g_cxy = row_allsum(g_cxy); g_cyy = row_allsum(g_cyy);
+            g_op = row_allsum(g_op);
+            g_c0 = row_allsum(g_c0); g_c1 = row_allsum(g_c1); g_c2 = row_allsum(g_c2);
+            g_d = row_allsum(g_d);
+            const int sub = lane & 15;
             float v = g_mx;
-            v = lane == 1 ? g_my : v; v = lane == 2 ? g_cxx : v; v = lane == 3 ? g_cxy : v; v = lane == 4 ? g_cyy : v;
-            v = lane == 5 ? g_op : v; v = lane == 6 ? g_c0 : v; v = lane == 7 ? g_c1 : v; v = lane == 8 ? g_c2 : v;
-            v = lane == 9 ? g_d : v;
-            if (lane < 10) atomicAdd(&sAcc[lane * ACC_STRIDE + j], v);
+            v = sub == 1 ? g_my : v; v = sub == 2 ? g_cxx : v; v = sub == 3 ? g_cxy : v; v = sub == 4 ? g_cyy : v;
+            v = sub == 5 ? g_op : v; v = sub == 6 ? g_c0 : v; v = sub == 7 ? g_c1 : v; v = sub == 8 ? g_c2 : v;
+            v = sub == 9 ? g_d : v;
+            if (sub < 10) atomicAdd(&sAcc[sub * ACC_STRIDE + j], v);
         }
         __syncthreads();
         // flush: 16 lanes own the 16-float gradient line of one staged Gaussian, so every atomic instruction covers four

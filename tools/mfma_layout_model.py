@@ -27,6 +27,28 @@ def mfma32(a, b, c):
     return out
 
 
+def mfma4(a, b, c):
+    """v_mfma_f32_4x4x1_16b_f32: 16 blocks; lane 4b+i holds A_b[i], lane 4b+j holds B_b[j], c[lane 4b+j, i] += A_b[i]*B_b[j]."""
+    out = c.copy()
+    for blk in range(16):
+        A = a[4 * blk:4 * blk + 4]
+        B = b[4 * blk:4 * blk + 4]
+        out[4 * blk:4 * blk + 4, :] += np.outer(B, A)   # [lane j][reg i]
+    return out
+
+
+def small_head(W2, b2, k, X, KT):
+    """k <= 4 outputs on the 4x4x1 MFMA (DenseIL::run4): returns out[lane, i]."""
+    acc = np.zeros((64, 4))
+    row = np.minimum(LANES & 3, k - 1)
+    for s in range(16):
+        for t in range(KT):
+            a = W2[row, KT * rho(s, 0) + KT * 4 * H + t]
+            acc = mfma4(a, X[t][:, s], acc)
+    tot = acc + acc[LANES ^ 32]
+    return tot + b2[np.minimum(np.arange(4), k - 1)][None, :]
+
+
 def dense_trunk(W0, b0, feat, FCH, OT):
     """feat[tile][lane, reg] chunk layout -> hid[ot][lane, reg] interleaved rows (row = OT*i + ot)."""
     Y = [np.zeros((64, 16)) for _ in range(OT)]
@@ -129,6 +151,9 @@ def check(WT, FCH, k, rng):
         o = dense_il(W2[32 * ot2:], b2[32 * ot2:], kk, h1, WT, 1, False)
         outs.append(tile_to_matrix(o, 1)[:, :kk])
     assert np.allclose(np.concatenate(outs, 1), out_ref), "L2"
+    if k <= 4:
+        o4 = small_head(W2, b2, k, h1, WT)
+        assert np.allclose(o4[:32, :k], out_ref) and np.allclose(o4[32:, :k], out_ref), "L2 small-head form"
     # backward: dh1 = G W2 (masked), dhid += dh1 W1, dfeat = dhid W0
     Gm = rng.standard_normal((32, k))
     dh1_ref = (Gm @ W2) * (h1_ref > 0)
