@@ -36,6 +36,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
+// same with block ABID of the A operand broadcast to all 16 blocks (CBSZ = 4)
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma4_bcast(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);
+}
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -563,6 +568,7 @@ struct BwdDev {
     int F;
     int head_slot[FDGS_NUM_HEADS];  // index of the head's dH1 slab
     int ntiles;                     // 32-Gaussian tiles (Npad / 32)
+    int small_heads;                // 1: dW2 of the k<=4 heads on the 4x4x1 MFMA with register-resident sums (FDGS_SMALL_HEADS)
     unsigned long long* prof;       // development builds (-DFDGS_PROFILE_D2): per-wave cycle sums per phase
 };
 #ifdef FDGS_PROFILE_D2
@@ -585,6 +591,16 @@ struct BwdLds {
 };
 __host__ __device__ __forceinline__ int head_row0(int hd) { return hd == 0 ? 0 : hd == 1 ? 3 : hd == 2 ? 6 : hd == 3 ? 10 : 11; }
 
+template <int NCH, int GQ>
+__device__ __forceinline__ void small_dw2_steps(f32x4* acc, float sa0, float sa1, const float* lds, int stride, int lane) {
+    if constexpr (GQ < 32) {
+#pragma unroll
+        for (int u = 0; u < NCH; u++)
+            acc[u] = mfma4_bcast<(GQ & 15)>(GQ < 16 ? sa0 : sa1, lds[GQ * stride + 64 * u + lane], acc[u]);
+        small_dw2_steps<NCH, GQ + 1>(acc, sa0, sa1, lds, stride, lane);
+    }
+}
+
 template <int WT, int FCH>
 __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     const fdgs_deform_params& p = d.p;
@@ -600,6 +616,18 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     __syncthreads();
     const int F = d.F;
 
+    // dW2 / db2 of the four k<=4 heads live in registers for the whole (persistent) kernel: 4x4x1 MFMA form, lane l register
+    // i = dW2[i][64u + l] (u-th 64-feature chunk); db2 partials per lane (block b = lane/4 holds Gaussians b and 16+b)
+    constexpr int NCH = W / 64;
+    f32x4 sw[4][NCH];
+    float sb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        sb[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NCH; u++) sw[q][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool small_on = d.small_heads != 0;
 #ifdef FDGS_PROFILE_D2
     unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
@@ -649,8 +677,16 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             // rows for the dW2 product (A-lane: output o = 32*ot2 + g, gaussian 2s+h) ...
             // (loads are unconditional -- columns past the head's k outputs lie inside the scratch buffer -- and zeroed by
             // a select: a conditional load becomes a branch that the compiler sinks to the use, exposing its latency)
+            const bool small = small_on && k <= 4;
             float ga[16];
-            {
+            float sa0 = 0.f, sa1 = 0.f;   // small path: A-lane 4b+i = G[gaussian b (+16)][output i]
+            if (small) {
+                const float* gp = d.s.G + (size_t)(n0 + (lane >> 2)) * GCOLS + off + (lane & 3);
+                sa0 = gp[0];
+                sa1 = gp[(size_t)16 * GCOLS];
+                sa0 = (lane & 3) < k ? sa0 : 0.f;
+                sa1 = (lane & 3) < k ? sa1 : 0.f;
+            } else {
                 const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + g;
 #pragma unroll
                 for (int s = 0; s < 16; s++) ga[s] = gp[(size_t)2 * s * GCOLS];
@@ -689,7 +725,19 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             __builtin_amdgcn_wave_barrier();
             D2_TICK(3);
             // ---- dW2[o][in] += sum_g G[g][o] * relu(h1)[g][in];  db2[o] += sum_g G[g][o]
-            for (int ot2 = 0; ot2 < nt2; ot2++) {
+            if (small) {
+                // one 4x4x1 MFMA per (Gaussian, 64-feature chunk): B-lane l = relu(h1)[gaussian][64u + l] straight from
+                // the transposed tile, A = the Gaussian's k gradient values broadcast from block gq%16 of sa0/sa1
+                auto small_dw2 = [&](f32x4* acc, float& bsum) {
+                    bsum += sa0 + sa1;
+                    small_dw2_steps<NCH, 0>(acc, sa0, sa1, lds, STRIDE, lane);
+                };
+                if (hd == FDGS_HEAD_POS) small_dw2(sw[0], sb[0]);
+                else if (hd == FDGS_HEAD_SCALE) small_dw2(sw[1], sb[1]);
+                else if (hd == FDGS_HEAD_ROT) small_dw2(sw[2], sb[2]);
+                else small_dw2(sw[3], sb[3]);
+            }
+            for (int ot2 = 0; ot2 < (small ? 0 : nt2); ot2++) {
                 const int o = ot2 * 32 + g;
                 if (ot2 > 0) {
                     const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + o;
@@ -780,6 +828,22 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         out[10] = prof_acc[10]; out[11] = prof_acc[11];
     }
 #endif
+    // the register-resident sums of the k<=4 heads join the LDS accumulators
+    if (small_on) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kq = head_k(q), r0 = head_row0(q);
+            if (!p.head_on[q]) continue;
+#pragma unroll
+            for (int u = 0; u < NCH; u++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (i < kq) atomicAdd(&accW2[(r0 + i) * W + 64 * u + lane], sw[q][u][i]);
+            float v = sb[q];   // lanes with equal (lane & 3): sum over the 16 blocks
+            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < kq) atomicAdd(&accB2[r0 + lane], v);
+        }
+    }
     // flush the workgroup's dW2 / db2 sums
     __syncthreads();
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
@@ -1199,7 +1263,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
     BwdDev bd;
-    bd.p = *p; bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32);
+    bd.p = *p; bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
     int slot = 0;
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
         bd.d_w2[hd] = g->d_w2[hd]; bd.d_b2[hd] = g->d_b2[hd];

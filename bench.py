@@ -154,6 +154,8 @@ def main():
             roof = dict(kernel=dom, bound="hbm", achieved=a / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=a / HBM_PEAK,
                         traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps)
 
+    if roof is not None:
+        roof.update(pmc_traffic(dom))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(fdgs, syn, pc, cams[args.warmup % len(cams)], target, dcfg, args.cpu_frames)
@@ -177,6 +179,26 @@ def main():
             "loss": {"l1": float(l1), "psnr": float(psnr)},
         }
         print(json.dumps(out))
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same bench command).  Corrections per
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; on gfx950 FETCH_SIZE reports half the bytes
+    of 16-B-per-lane streaming reads, which is what the MLP / per-Gaussian kernels issue, so it is doubled.  WRITE_SIZE is
+    uncalibrated there and taken as reported.  null when no PMC artefact is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return {"traffic": None}
+    d = json.load(open(files[-1]))
+    k = d.get(kernel)
+    if not k:
+        return {"traffic": None, "traffic_source": os.path.basename(files[-1]) + " (kernel not profiled)"}
+    fetch, write = k.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024, k.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
+    return {"traffic": 2 * fetch + write, "traffic_unit": "bytes/launch",
+            "traffic_detail": {"FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_bytes_corrected_x2": 2 * fetch, "WRITE_SIZE_bytes": write},
+            "traffic_source": "profiles/" + os.path.basename(files[-1])}
 
 
 def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):

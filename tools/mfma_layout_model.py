@@ -189,6 +189,24 @@ def check(WT, FCH, k, rng):
                     if orow < kk:
                         dW2[32 * ot2 + orow, tb * 32 + (lane & 31)] += acc[lane, r]
     assert np.allclose(dW2, Gm.T @ h1_ref), "dW2"
+    if k <= 4:
+        # register-resident 4x4x1 form (small_dw2_steps): A broadcast from block gq%16 of sa0/sa1, B = lds row gq
+        sa = [np.where((LANES & 3) < k, Gm[16 * x + (LANES >> 2), np.minimum(LANES & 3, k - 1)], 0.0) for x in range(2)]
+        NCH = W // 64
+        acc = [np.zeros((64, 4)) for _ in range(NCH)]
+        for gq in range(32):
+            blk = gq & 15
+            a_b = np.tile(sa[gq >> 4][4 * blk:4 * blk + 4], 16)          # CBSZ=4, ABID=blk: block blk of A feeds every block
+            for u in range(NCH):
+                acc[u] = mfma4(a_b, lds[gq, 64 * u + LANES], acc[u])
+        dW2s = np.zeros((k, W))
+        for u in range(NCH):
+            for i in range(k):
+                dW2s[i, 64 * u + LANES] = acc[u][:, i]
+        assert np.allclose(dW2s, Gm.T @ h1_ref), "dW2 small-head form"
+        sb = sa[0] + sa[1]
+        db = np.array([sb[(LANES & 3) == i].sum() for i in range(k)])
+        assert np.allclose(db, Gm.sum(0)), "db2 small-head form"
     return True
 
 
