@@ -87,7 +87,9 @@ struct DeformDev {
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
 };
 
-// 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian
+// 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian.
+// Texel addresses are 32-bit byte offsets from the (wave-uniform) plane pointer: one VALU op per address and the
+// SGPR-base + VGPR-offset load form, instead of 64-bit multiply-adds per corner (planes are < 2^32 bytes by validation).
 __device__ __forceinline__ float4 gather_chunk(const fdgs_deform_params& p, int f0, const float* q) {
     const int lvl = f0 / p.C, c0 = f0 - lvl * p.C;
     float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -97,11 +99,14 @@ __device__ __forceinline__ float4 gather_chunk(const fdgs_deform_params& p, int 
         plane_axes(k, a, b);
         const int Wd = p.res[lvl][a], Hd = p.res[lvl][b];
         const AxisSample sx = axis_sample(q[a], Wd), sy = axis_sample(q[b], Hd);
-        const float* P = p.planes[lvl][k];
-        const float4 v00 = *reinterpret_cast<const float4*>(P + ((size_t)(sy.i0 * Wd + sx.i0) * p.C + c0));
-        const float4 v01 = *reinterpret_cast<const float4*>(P + ((size_t)(sy.i0 * Wd + sx.i1) * p.C + c0));
-        const float4 v10 = *reinterpret_cast<const float4*>(P + ((size_t)(sy.i1 * Wd + sx.i0) * p.C + c0));
-        const float4 v11 = *reinterpret_cast<const float4*>(P + ((size_t)(sy.i1 * Wd + sx.i1) * p.C + c0));
+        const char* P = reinterpret_cast<const char*>(p.planes[lvl][k]);
+        const uint32_t texel = (uint32_t)p.C * 4u, cb = (uint32_t)c0 * 4u;
+        const uint32_t r0 = (uint32_t)(sy.i0 * Wd) * texel + cb, r1 = (uint32_t)(sy.i1 * Wd) * texel + cb;
+        const uint32_t x0 = (uint32_t)sx.i0 * texel, x1 = (uint32_t)sx.i1 * texel;
+        const float4 v00 = *reinterpret_cast<const float4*>(P + (r0 + x0));
+        const float4 v01 = *reinterpret_cast<const float4*>(P + (r0 + x1));
+        const float4 v10 = *reinterpret_cast<const float4*>(P + (r1 + x0));
+        const float4 v11 = *reinterpret_cast<const float4*>(P + (r1 + x1));
         const float w00 = sx.w0 * sy.w0, w01 = sx.w1 * sy.w0, w10 = sx.w0 * sy.w1, w11 = sx.w1 * sy.w1;
         prod.x *= v00.x * w00 + v01.x * w01 + v10.x * w10 + v11.x * w11;
         prod.y *= v00.y * w00 + v01.y * w01 + v10.y * w10 + v11.y * w11;
@@ -492,13 +497,22 @@ struct PrepArgs {
     float *d_xyz, *d_scales, *d_rot, *d_opacity, *d_shs_dc, *d_shs_rest;
     float* G;
 };
+// One wave per 64 consecutive Gaussians.  Every array is written as one contiguous block per wave (G: 16 KB, d_shs:
+// 12 KB, d_xyz: 768 B ...) by staging the per-Gaussian rows in LDS and walking the block linearly, lane-consecutive:
+// the round-1 kernel wrote 4..16-byte pieces at 12..256-byte strides and rocprofv3 showed 2.1x write and 2.4x fetch
+// amplification on it (profiles/r01c_pmc_*).
 __global__ void __launch_bounds__(256) deform_bwd_prep_kernel(PrepArgs a) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= a.Npad) return;
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* small = lds_all + wave * 64 * 64;   // [64][16]: the 11 pre-activation gradients of the k<=4 heads (+ padding)
+    float* sh = small + 64 * 16;               // [64][48]: g_shs rows
+    const int n0 = (blockIdx.x * 4 + wave) * 64;
+    if (n0 >= a.Npad) return;
+    const int n = n0 + lane;
+    const int nvalid = a.N - n0 < 64 ? (a.N - n0 > 0 ? a.N - n0 : 0) : 64;   // Gaussians of this wave that exist
     float row[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) row[i] = 0.f;
-    float4* G4 = reinterpret_cast<float4*>(a.G + (size_t)n * GCOLS);
     if (n < a.N) {
         if (a.g_xyz) { row[0] = a.g_xyz[3 * (size_t)n]; row[1] = a.g_xyz[3 * (size_t)n + 1]; row[2] = a.g_xyz[3 * (size_t)n + 2]; }
         if (a.g_scales) {
@@ -528,31 +542,74 @@ __global__ void __launch_bounds__(256) deform_bwd_prep_kernel(PrepArgs a) {
             const float o = a.activate ? a.out_opacity[n] : 0.f;
             row[10] = a.activate ? go * o * (1.f - o) : go;
         }
-        if (a.d_xyz) { a.d_xyz[3 * (size_t)n] += row[0]; a.d_xyz[3 * (size_t)n + 1] += row[1]; a.d_xyz[3 * (size_t)n + 2] += row[2]; }
-        if (a.d_scales) { a.d_scales[3 * (size_t)n] += row[3]; a.d_scales[3 * (size_t)n + 1] += row[4]; a.d_scales[3 * (size_t)n + 2] += row[5]; }
-        if (a.d_rot) {
-            float4 v = reinterpret_cast<float4*>(a.d_rot)[n];
-            v.x += row[6]; v.y += row[7]; v.z += row[8]; v.w += row[9];
-            reinterpret_cast<float4*>(a.d_rot)[n] = v;
-        }
-        if (a.d_opacity) a.d_opacity[n] += row[10];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) G4[i] = make_float4(row[4 * i], row[4 * i + 1], row[4 * i + 2], row[4 * i + 3]);
-    for (int i = 0; i < 12; i++) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < a.N && a.g_shs) {
-            v = *reinterpret_cast<const float4*>(a.g_shs + 48 * (size_t)n + 4 * i);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < 4; i++)
+        reinterpret_cast<float4*>(small)[lane * 4 + i] = make_float4(row[4 * i], row[4 * i + 1], row[4 * i + 2], row[4 * i + 3]);
+    // g_shs block of this wave: [64][48] floats = 768 float4, contiguous in memory
+    const float4* gsh4 = a.g_shs ? reinterpret_cast<const float4*>(a.g_shs + (size_t)n0 * 48) : nullptr;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int m = 4 * i + c;
-                if (m < 3) { if (a.d_shs_dc) a.d_shs_dc[(size_t)a.dc_stride * n + m] += vv[c]; }
-                else if (a.d_shs_rest) a.d_shs_rest[(size_t)a.rest_stride * n + (m - 3)] += vv[c];
+    for (int j = 0; j < 12; j++) {
+        const int v = j * 64 + lane;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gsh4 && v < nvalid * 12) x = gsh4[v];
+        reinterpret_cast<float4*>(sh)[v] = x;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- packed gradient rows G[n][64] = [small 16 | shs 48] (padded rows n >= N are zero)
+    {
+        float4* G4 = reinterpret_cast<float4*>(a.G + (size_t)n0 * GCOLS);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int v = j * 64 + lane, r = v >> 4, c4 = v & 15;
+            G4[v] = c4 < 4 ? reinterpret_cast<const float4*>(small)[r * 4 + c4] : reinterpret_cast<const float4*>(sh)[r * 12 + (c4 - 4)];
+        }
+    }
+    // ---- identity paths (out = in + delta): accumulate into the parameter gradients, block-linear
+    if (a.d_shs_dc && a.d_shs_rest && a.dc_stride == 48 && a.rest_stride == 48 && a.d_shs_rest == a.d_shs_dc + 3) {
+        float4* d4 = reinterpret_cast<float4*>(a.d_shs_dc + (size_t)n0 * 48);   // one combined [N,16,3] tensor
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int v = j * 64 + lane;
+            if (v < nvalid * 12) {
+                float4 x = d4[v];
+                const float4 y = reinterpret_cast<const float4*>(sh)[v];
+                x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+                d4[v] = x;
             }
         }
-        G4[4 + i] = v;
+    } else {
+        if (a.d_shs_dc) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int idx = j * 64 + lane, r = idx / 3, c = idx - 3 * r;
+                if (r < nvalid) a.d_shs_dc[(size_t)(n0 + r) * a.dc_stride + c] += sh[r * 48 + c];
+            }
+        }
+        if (a.d_shs_rest) {
+            for (int j = 0; j < 45; j++) {
+                const int idx = j * 64 + lane, r = idx / 45, c = idx - 45 * r;
+                if (r < nvalid) a.d_shs_rest[(size_t)(n0 + r) * a.rest_stride + c] += sh[r * 48 + 3 + c];
+            }
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int idx = j * 64 + lane, r = idx / 3, c = idx - 3 * r;
+        if (r < nvalid) {
+            if (a.d_xyz) a.d_xyz[(size_t)n0 * 3 + idx] += small[r * 16 + c];
+            if (a.d_scales) a.d_scales[(size_t)n0 * 3 + idx] += small[r * 16 + 3 + c];
+        }
+    }
+    if (a.d_rot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = j * 64 + lane, r = idx >> 2, c = idx & 3;
+            if (r < nvalid) a.d_rot[(size_t)n0 * 4 + idx] += small[r * 16 + 6 + c];
+        }
+    }
+    if (a.d_opacity && lane < nvalid) a.d_opacity[n] += small[lane * 16 + 10];
 }
 
 // ------------------------------------------------------------------------------------------------ D2 backward-data
@@ -1140,7 +1197,11 @@ static int validate_deform(const fdgs_deform_params* p) {
     FDGS_REQUIRE(F <= 128, "C*L must be <= 128");
     for (int l = 0; l < p->L; l++) {
         for (int k = 0; k < 6; k++) FDGS_REQUIRE(p->planes[l][k] != nullptr, "plane pointer is NULL");
-        for (int i = 0; i < 4; i++) FDGS_REQUIRE(p->res[l][i] >= 2, "plane resolution must be >= 2");
+        for (int i = 0; i < 4; i++) FDGS_REQUIRE(p->res[l][i] >= 2 && p->res[l][i] <= 4096, "plane resolution must be in [2, 4096]");
+        for (int k = 0; k < 6; k++) {
+            const int a = k < 3 ? 0 : (k < 5 ? 1 : 2), b = k < 3 ? k + 1 : (k < 5 ? k - 1 : 3);
+            FDGS_REQUIRE((long long)p->res[l][a] * p->res[l][b] * p->C * 4 < (1ll << 31), "plane larger than 2 GiB");
+        }
     }
     FDGS_REQUIRE(p->w0 && p->b0, "trunk weights missing");
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++)

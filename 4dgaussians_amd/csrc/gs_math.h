@@ -182,8 +182,10 @@ FDGS_HD uint32_t sh_to_rgb(int deg, const float* sh, const float* p, const float
     sh_basis(deg, dx, dy, dz, b);
     int nc = (deg + 1) * (deg + 1);
     float r[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < nc; k++) {
-        r[0] += b[k] * sh[3 * k + 0]; r[1] += b[k] * sh[3 * k + 1]; r[2] += b[k] * sh[3 * k + 2];
+    // fixed trip count + predicate: every array index is a compile-time constant (a runtime bound puts b[] / sh[] in scratch)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nc) { r[0] += b[k] * sh[3 * k + 0]; r[1] += b[k] * sh[3 * k + 1]; r[2] += b[k] * sh[3 * k + 2]; }
     }
     uint32_t cl = 0;
 #pragma unroll
@@ -210,9 +212,14 @@ FDGS_HD void sh_bwd(int deg, const float* sh, const float* p, const float* campo
     sh_basis(deg, x, y, z, b);
     int nc = (deg + 1) * (deg + 1);
     float v[16];
-    for (int k = 0; k < nc; k++) {
-        dL_dsh[3 * k + 0] = b[k] * g[0]; dL_dsh[3 * k + 1] = b[k] * g[1]; dL_dsh[3 * k + 2] = b[k] * g[2];
-        v[k] = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nc) {
+            dL_dsh[3 * k + 0] = b[k] * g[0]; dL_dsh[3 * k + 1] = b[k] * g[1]; dL_dsh[3 * k + 2] = b[k] * g[2];
+            v[k] = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
+        } else {
+            v[k] = 0.f;
+        }
     }
     float ddx = 0.f, ddy = 0.f, ddz = 0.f;
     if (deg > 0) {

@@ -111,67 +111,96 @@ struct PreBwdArgs {
     float *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drot, *dL_dcov3D;
 };
 
+// Block-linear store of K floats per Gaussian for the 64 Gaussians of a wave: lanes park their K values in LDS as
+// [gaussian][K] (the memory layout of the output block) and the wave then copies the block with lane-consecutive
+// addresses.  Stores of 4..24 bytes at 12..192-byte strides cost 3.7x write amplification in the round-1 kernel
+// (rocprofv3 WRITE_SIZE 314 MB for 85 MB of results, profiles/r01c_pmc_write_size.txt).
+template <int K>
+__device__ __forceinline__ void wave_store_rows(float* __restrict__ out_block, const float* vals, int nvalid, float* buf, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 4; i++)
+            reinterpret_cast<float4*>(buf)[lane * (K / 4) + i] = make_float4(vals[4 * i], vals[4 * i + 1], vals[4 * i + 2], vals[4 * i + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < K / 4; j++) {
+            const int v = j * 64 + lane;
+            if (v < nvalid * (K / 4)) reinterpret_cast<float4*>(out_block)[v] = reinterpret_cast<const float4*>(buf)[v];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; i++) buf[lane * K + i] = vals[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const int idx = j * 64 + lane;
+            if (idx < nvalid * K) out_block[idx] = buf[idx];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.P) return;
-    if (a.tiles[i] == 0) {
-        // culled / zero-area Gaussians: every output row is written here (zeros), so the caller needs no memsets
-        a.dL_dmeans2D[3 * (size_t)i] = 0.f; a.dL_dmeans2D[3 * (size_t)i + 1] = 0.f; a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
-        a.dL_dopacity[i] = 0.f;
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * 48];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* buf = lds_all + wave * 64 * 48;
+    const int n0 = (blockIdx.x * 4 + wave) * 64;
+    if (n0 >= a.P) return;
+    const int i = n0 + lane;
+    const int nvalid = a.P - n0 < 64 ? a.P - n0 : 64;
+    const bool active = i < a.P && a.tiles[i] != 0;
+    // every output row is written (zeros for culled / zero-area Gaussians): the caller needs no memsets
+    float m2d[3] = {0.f, 0.f, 0.f}, dop = 0.f, drgb[3] = {0.f, 0.f, 0.f}, dcov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dmean[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsh[48];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { a.dL_dcolors[3 * (size_t)i + k] = 0.f; a.dL_dmeans3D[3 * (size_t)i + k] = 0.f; }
+    for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+    if (active) {
+        CamConst c;
+        load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
+        float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
+        float c6[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
+        for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
+        const float4* ga = reinterpret_cast<const float4*>(a.gacc + 16 * (size_t)i);
+        const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+        // mean2D gradient is handed back in NDC units (d pix / d ndc = W/2, H/2), like the reference's viewspace grad
+        m2d[0] = g0.x * 0.5f * (float)a.W; m2d[1] = g0.y * 0.5f * (float)a.H;
+        dop = g1.y;
+        drgb[0] = g1.z; drgb[1] = g1.w; drgb[2] = g2.x;
+        float dconic[3] = {g0.z, g0.w, g1.x};
+        project_bwd(c, p, c6, dconic, g2.y, m2d[0], m2d[1], dmean, dcov6);
         if (a.shs) {
-            float* out = a.dL_dsh + (size_t)i * a.M * 3;
-            for (int k = 0; k < a.M * 3; k++) out[k] = 0.f;
+            const float* sh = a.shs + (size_t)i * a.M * 3;
+            sh_bwd(c.D, sh, p, c.campos, a.clamped[i], drgb, dsh, dmean);
         }
         if (!a.has_cov_precomp) {
-            a.dL_dscales[3 * (size_t)i] = 0.f; a.dL_dscales[3 * (size_t)i + 1] = 0.f; a.dL_dscales[3 * (size_t)i + 2] = 0.f;
-            reinterpret_cast<float4*>(a.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
+            const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
+            float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            cov3d_bwd(s, c.scale_mod, q, dcov6, ds, dq);
         }
-        return;
     }
-    CamConst c;
-    load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
-    float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
-    float c6[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
-    const float4* ga = reinterpret_cast<const float4*>(a.gacc + 16 * (size_t)i);
-    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
-    // mean2D gradient is handed back in NDC units (d pix / d ndc = W/2, H/2), like the reference's viewspace grad
-    float gx = g0.x * 0.5f * (float)a.W, gy = g0.y * 0.5f * (float)a.H;
-    a.dL_dmeans2D[3 * (size_t)i] = gx;
-    a.dL_dmeans2D[3 * (size_t)i + 1] = gy;
-    a.dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
-    a.dL_dopacity[i] = g1.y;
-    float drgb[3] = {g1.z, g1.w, g2.x};
-    a.dL_dcolors[3 * (size_t)i] = drgb[0]; a.dL_dcolors[3 * (size_t)i + 1] = drgb[1]; a.dL_dcolors[3 * (size_t)i + 2] = drgb[2];
-    float dconic[3] = {g0.z, g0.w, g1.x};
-    float dmean[3] = {0.f, 0.f, 0.f}, dcov6[6];
-    project_bwd(c, p, c6, dconic, g2.y, gx, gy, dmean, dcov6);
-#pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dcov6[k];
+    wave_store_rows<3>(a.dL_dmeans2D + (size_t)n0 * 3, m2d, nvalid, buf, lane);
+    wave_store_rows<3>(a.dL_dcolors + (size_t)n0 * 3, drgb, nvalid, buf, lane);
+    wave_store_rows<3>(a.dL_dmeans3D + (size_t)n0 * 3, dmean, nvalid, buf, lane);
+    wave_store_rows<6>(a.dL_dcov3D + (size_t)n0 * 6, dcov6, nvalid, buf, lane);
+    if (i < a.P) a.dL_dopacity[i] = dop;
     if (a.shs) {
-        const float* sh = a.shs + (size_t)i * a.M * 3;
-        float dsh[48];
-        sh_bwd(c.D, sh, p, c.campos, a.clamped[i], drgb, dsh, dmean);
-        int nc = (c.D + 1) * (c.D + 1);
-        float* out = a.dL_dsh + (size_t)i * a.M * 3;
-        for (int k = 0; k < nc * 3; k++) out[k] = dsh[k];
-        for (int k = nc * 3; k < a.M * 3; k++) out[k] = 0.f;   // coefficients above the active degree
+        if (a.M == 16) {
+            wave_store_rows<48>(a.dL_dsh + (size_t)n0 * 48, dsh, nvalid, buf, lane);
+        } else if (i < a.P) {
+            float* out = a.dL_dsh + (size_t)i * a.M * 3;
+#pragma unroll
+            for (int k = 0; k < 48; k++) if (k < a.M * 3) out[k] = dsh[k];
+        }
     }
-    a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
-    a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     if (!a.has_cov_precomp) {
-        float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
-        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[i];
-        float q[4] = {qv.x, qv.y, qv.z, qv.w};
-        float ds[3], dq[4];
-        cov3d_bwd(s, c.scale_mod, q, dcov6, ds, dq);
-        a.dL_dscales[3 * (size_t)i] = ds[0]; a.dL_dscales[3 * (size_t)i + 1] = ds[1]; a.dL_dscales[3 * (size_t)i + 2] = ds[2];
-        reinterpret_cast<float4*>(a.dL_drot)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        wave_store_rows<3>(a.dL_dscales + (size_t)n0 * 3, ds, nvalid, buf, lane);
+        if (i < a.P) reinterpret_cast<float4*>(a.dL_drot)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
 }
 
