@@ -36,13 +36,26 @@ void timing_end(void* rec, hipStream_t stream) {
 }
 
 // [sum |a-b|, sum (a-b)^2, n] with optional dL/da = sign(a-b)*scale (utils/loss_utils.py:20-21 of the reference)
-__global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, const float* __restrict__ a, const float* __restrict__ b,
+__global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, size_t n4, const float* __restrict__ a, const float* __restrict__ b,
                                                        float scale, float* __restrict__ grad, float* __restrict__ acc) {
     float s1 = 0.f, s2 = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float d = a[i] - b[i];
+    // n4 = number of 16-byte groups handled with float4 accesses (0 when a pointer is not 16-byte aligned), scalar tail
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    float4* g4 = reinterpret_cast<float4*>(grad);
+    auto one = [&](float x, float y) {
+        const float d = x - y;
         s1 += fabsf(d); s2 += d * d;
-        if (grad) grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        return d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = a4[i], y = b4[i];
+        const float4 g = make_float4(one(x.x, y.x), one(x.y, y.y), one(x.z, y.z), one(x.w, y.w));
+        if (grad) g4[i] = g;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float g = one(a[i], b[i]);
+        if (grad) grad[i] = g;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -107,9 +120,12 @@ extern "C" int fdgs_l1_stats(void* stream_, size_t n, const float* a, const floa
     FDGS_REQUIRE(a && b && acc, "NULL pointer");
     if (n == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(256), 0, stream, n, a, b, grad_scale, grad_out_opt, acc); }
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_out_opt) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    int blocks = (int)(((aligned ? n / 4 : n) + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;   // two atomics per workgroup on the same two words: keep the tail short
+    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(256), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc); }
     FDGS_LAUNCH_CHECK("l1_stats", 0, stream);
     return FDGS_OK;
 }

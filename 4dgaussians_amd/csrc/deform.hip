@@ -685,6 +685,12 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         for (int u = 0; u < NCH; u++) sw[q][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool small_on = d.small_heads != 0;
+    // dW2 of the 48-row SH head: the four waves of the workgroup pool their transposed relu(h1) tiles (128 Gaussians) and
+    // every wave OWNS one 32-column block of dW2 for both 32-row tiles, so its sums go into the LDS accumulator with plain
+    // read-add-write instead of atomics.  (The per-wave form needed ~96 ds_add_f32 per tile to merge the waves' partial
+    // sums: ~30 k cycles per tile, 9 % of the kernel, in-kernel cycle profile of round 1.)  Two workgroup barriers per tile.
+    constexpr int NU = WT == 4 ? 2 : 1;            // (ot2, tb) units per wave: WT=4: (0,w),(1,w); WT=2: (w>>1, w&1)
+    bool tiles_shared = false;   // another wave may still be reading this wave's tile: barrier before overwriting it
 #ifdef FDGS_PROFILE_D2
     unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
@@ -743,12 +749,15 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 sa1 = gp[(size_t)16 * GCOLS];
                 sa0 = (lane & 3) < k ? sa0 : 0.f;
                 sa1 = (lane & 3) < k ? sa1 : 0.f;
-            } else {
+            } else if (k <= 32) {   // (the 48-row head takes the cooperative path and loads its rows there)
                 const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + g;
 #pragma unroll
                 for (int s = 0; s < 16; s++) ga[s] = gp[(size_t)2 * s * GCOLS];
 #pragma unroll
                 for (int s = 0; s < 16; s++) ga[s] = g < k ? ga[s] : 0.f;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; s++) ga[s] = 0.f;
             }
             {
                 f32x16 h1[WT];
@@ -764,19 +773,27 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                     }
                 }
                 // transposed copy relu(h1)[gaussian][feature] for the dW2 product
+                if (tiles_shared) { __syncthreads(); tiles_shared = false; }
                 store_il<WT>(lds + g * STRIDE, h1, h);
             }
             // ... the first operands of the long transposed product, and of dh1 = W2^T G_head (k-steps over the head's
             // outputs, two per MFMA: A = W2 row o, B = G[gaussian][o])
             DenseT<WT, WT, true, 4> B1;
-            B1.setup(p.w1[hd], W, W, g, h);
-            B1.preload();
             const float* w2p = p.w2[hd] + WT * g;
             const int nsteps = (k + 1) >> 1;
             auto ldA = [&](int s) { int o = 2 * s + h; o = o < k ? o : k - 1; return ldv<WT>(w2p + (size_t)o * W); };
             auto ldB = [&](int s) { const int o = 2 * s + h; const float v = Grow[off + o]; return o < k ? v : 0.f; };
-            AVec<WT> a0 = ldA(0), a1 = ldA(1 < nsteps ? 1 : 0), a2 = ldA(2 < nsteps ? 2 : 0);
-            float b0 = ldB(0), b1 = 1 < nsteps ? ldB(1) : 0.f, b2 = 2 < nsteps ? ldB(2) : 0.f;
+            AVec<WT> a0, a1, a2;
+            float b0, b1, b2;
+            auto early_requests = [&]() {
+                B1.setup(p.w1[hd], W, W, g, h);
+                B1.preload();
+                a0 = ldA(0); a1 = ldA(1 < nsteps ? 1 : 0); a2 = ldA(2 < nsteps ? 2 : 0);
+                b0 = ldB(0); b1 = ldB(1 < nsteps ? 1 : 0); b2 = ldB(2 < nsteps ? 2 : 0);
+                b1 = 1 < nsteps ? b1 : 0.f; b2 = 2 < nsteps ? b2 : 0.f;
+            };
+            const bool coop = !small && k > 32;
+            if (!coop) early_requests();   // (the cooperative SH block needs the registers: requests follow it)
             __builtin_amdgcn_sched_barrier(0);   // keep these requests ahead of the dW2 block
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -794,7 +811,49 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 else if (hd == FDGS_HEAD_ROT) small_dw2(sw[2], sb[2]);
                 else small_dw2(sw[3], sb[3]);
             }
-            for (int ot2 = 0; ot2 < (small ? 0 : nt2); ot2++) {
+            if (coop) {
+                __syncthreads();                                   // all four tiles of the workgroup are written
+                const int nwg0 = (tile - wave) * 32;               // first Gaussian of the workgroup's four tiles
+#pragma unroll
+                for (int j = 0; j < NU; j++) {
+                    const int ot2 = WT == 4 ? j : (wave >> 1), tb = WT == 4 ? wave : (wave & 1);
+                    const int o = ot2 * 32 + g;
+                    const float* gp = d.s.G + (size_t)(nwg0 + h) * GCOLS + off + o;
+                    const float* bp = lds_all + tb * 32 + g;
+                    float gq[2][16];
+                    f32x16 accS = zero16();
+                    float asumS = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 16; s++) gq[0][s] = gp[(size_t)2 * s * GCOLS];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {                  // 4 chunks of 16 k-steps = the 4 tiles (32 Gaussians each)
+                        if (c + 1 < 4) {
+#pragma unroll
+                            for (int s = 0; s < 16; s++) gq[(c + 1) & 1][s] = gp[(size_t)(32 * (c + 1) + 2 * s) * GCOLS];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 16; s++) {
+                            const float a = o < k ? gq[c & 1][s] : 0.f;
+                            asumS += a;
+                            accS = mfma32(a, bp[c * LD::TILE_FLOATS + (2 * s + h) * STRIDE], accS);
+                        }
+                    }
+                    // this wave is the only writer of these cells: plain LDS read-add-write
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int orow = ot2 * 32 + rho(r, h);
+                        if (orow < k) accW2[(row0 + orow) * W + tb * 32 + g] += accS[r];
+                    }
+                    if (tb == 0) {   // db2: one wave per row tile
+                        asumS += __shfl_xor(asumS, 32, 64);
+                        if (h == 0 && o < k) accB2[row0 + o] += asumS;
+                    }
+                }
+                tiles_shared = true;
+                early_requests();
+            }
+            for (int ot2 = 0; ot2 < ((small || coop) ? 0 : nt2); ot2++) {
                 const int o = ot2 * 32 + g;
                 if (ot2 > 0) {
                     const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + o;
