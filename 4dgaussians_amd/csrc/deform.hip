@@ -1480,7 +1480,9 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
-        const int lds_budget = tunable("FDGS_PG_LDS", 1) ? 64 * 1024 : 0;  // bytes per workgroup (2 workgroups / CU)
+        // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
+        // atomics on ~128 hot lines, is 4x slower than scattered atomics)
+        const int lds_budget = tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0;
         int used = 0;
         for (int l = 0; l < FDGS_MAX_LEVELS; l++)
             for (int sl = 0; sl < 3; sl++) ga.lds_off[l][sl] = -1;
@@ -1504,6 +1506,16 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         ga.per_block = per_block;
         const int blocks = cdiv(p->N, per_block);
         const size_t lds_bytes = (size_t)used * 4;
+        if (lds_bytes > 64 * 1024) {   // above the default dynamic-LDS limit: opt in once per kernel
+            static bool raised16 = false, raised32 = false;
+            bool& raised = p->C == 16 ? raised16 : raised32;
+            if (!raised) {
+                const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_kernel<16>)
+                                            : reinterpret_cast<const void*>(&deform_plane_grad_kernel<32>);
+                FDGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+        }
         if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<16>), dim3(blocks), dim3(PG_THREADS), lds_bytes, stream, ga); }
         else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_kernel<32>), dim3(blocks), dim3(PG_THREADS), lds_bytes, stream, ga); }
         FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
