@@ -5,7 +5,7 @@ raises.  (The oracle under oracle/ is test infrastructure and is never imported 
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfdgs.so")
@@ -50,6 +50,16 @@ class DeformGrads(Structure):
                 ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p)]
 
 
+class RegPlane(Structure):
+    _fields_ = [("plane", c_void_p), ("grad_opt", c_void_p), ("H", c_int), ("W", c_int), ("C", c_int),
+                ("w_smooth", c_float), ("w_l1", c_float)]
+
+
+class AdamTensor(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_size_t),
+                ("lr", c_float), ("step", c_int)]
+
+
 # every symbol include/fdgs.h declares: (restype, argtypes)
 SYMBOLS = {
     "fdgs_last_error": (c_char_p, []),
@@ -73,6 +83,8 @@ SYMBOLS = {
     "fdgs_deform_bwd_scratch_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),
     "fdgs_l1_stats": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "fdgs_plane_regulation": (c_int, [c_void_p, c_int, POINTER(RegPlane), c_float, c_void_p, c_void_p]),
+    "fdgs_adam_step": (c_int, [c_void_p, c_int, POINTER(AdamTensor), c_double, c_double, c_double]),
 }
 
 _lib = None

@@ -207,6 +207,41 @@ int fdgs_deform_bwd(void* stream, const fdgs_deform_params* p, const fdgs_deform
 int fdgs_l1_stats(void* stream, size_t n, const float* a, const float* b, float grad_scale, float* grad_out_opt,
                   float* acc);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * HexPlane regulariser: replaces GaussianModel.compute_regulation (scene/gaussian_model.py:538-577 with
+ * compute_plane_smoothness of scene/regulation.py:22-28; evaluated at train.py:208-211 every fine iteration).
+ *   loss += sum_planes [ w_smooth * mean_{C,H-2,W} (p[h+2] - 2 p[h+1] + p[h])^2 + w_l1 * mean |1 - p| ]
+ * The caller passes, per plane, the weight that the reference applies to it: planes (0,1,3) of a level get
+ * w_smooth = plane_tv_weight, planes (2,4,5) get w_smooth = time_smoothness_weight and w_l1 = l1_time_planes_weight.
+ * Planes are channels-last [H][W][C] device arrays (as in fdgs_deform_params).  One launch computes the value
+ * (accumulated into *loss_acc_opt, caller zero-fills) and, for planes with grad_opt != NULL, accumulates
+ * grad_scale * (*grad_scale_dev_opt, 1 if NULL) * dloss/dplane into grad_opt (same layout).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct fdgs_reg_plane {
+    const float* plane;   /* [H][W][C] */
+    float* grad_opt;      /* [H][W][C], accumulated (+=) */
+    int H, W, C;
+    float w_smooth;       /* weight of the second-difference term (0: skipped) */
+    float w_l1;           /* weight of mean |1 - p| (0: skipped) */
+} fdgs_reg_plane;
+int fdgs_plane_regulation(void* stream, int nplanes, const fdgs_reg_plane* planes /* host array */, float grad_scale,
+                          const float* grad_scale_dev_opt, float* loss_acc_opt);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer step: replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of the reference (scene/gaussian_model.py:184,
+ * train.py:291) for all parameter tensors of a step in one launch.  Per tensor: element count, the four device
+ * arrays (same memory order, 16-byte aligned), the group's learning rate and the tensor's step count AFTER this step
+ * (t >= 1, bias corrections 1 - beta^t).  No weight decay, no amsgrad (the reference uses neither).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct fdgs_adam_tensor {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    size_t n;
+    float lr;
+    int step;
+} fdgs_adam_tensor;
+int fdgs_adam_step(void* stream, int ntensors, const fdgs_adam_tensor* tensors /* host array */, double beta1, double beta2,
+                   double eps);   /* doubles: 1 - beta and the bias corrections are formed in double like torch does */
+
 #ifdef __cplusplus
 }
 #endif
