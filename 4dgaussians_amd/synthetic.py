@@ -172,6 +172,18 @@ class SynthModel(torch.nn.Module):
         self.opacity_activation = torch.sigmoid
         self.to(device)
 
+    def optimizer_groups(self, lr=0.0):
+        """The eight parameter groups of GaussianModel.training_setup (scene/gaussian_model.py:165-183), same names/order."""
+        d = self._deformation
+        return [{"params": [self._xyz], "lr": lr, "name": "xyz"},
+                {"params": list(d.get_mlp_parameters()), "lr": lr, "name": "deformation"},
+                {"params": list(d.get_grid_parameters()), "lr": lr, "name": "grid"},
+                {"params": [self._features_dc], "lr": lr, "name": "f_dc"},
+                {"params": [self._features_rest], "lr": lr, "name": "f_rest"},
+                {"params": [self._opacity], "lr": lr, "name": "opacity"},
+                {"params": [self._scaling], "lr": lr, "name": "scaling"},
+                {"params": [self._rotation], "lr": lr, "name": "rotation"}]
+
     @property
     def get_xyz(self):
         return self._xyz

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--workload", default="cfg4_dynerf_300k_1352x1014", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary full-iteration measurement")
     args = ap.parse_args()
 
     fdgs = importlib.import_module("4dgaussians_amd")
@@ -156,6 +157,43 @@ def main():
 
     if roof is not None:
         roof.update(pmc_traffic(dom))
+
+    # ---- secondary measurement: one full fine-stage iteration of train.py (180-292) without data loading / densification:
+    # render fwd+bwd + L1 statistics + HexPlane regulariser fwd+bwd (train.py:208-211) + optimizer step (:291-292), the
+    # last two through the fused kernels of the "next" rows.  lr = 0 keeps the scene identical from step to step.
+    train = None
+    if not args.no_train_step:
+        opt = fdgs.FusedAdam(pc.optimizer_groups(lr=0.0), lr=0.0, eps=1e-15)
+
+        def train_iter(i):
+            step(i)
+            reg = fdgs.compute_regulation(pc, 0.01, 0.0001, 0.0001)     # arguments/__init__.py:85-87 defaults
+            reg.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+
+        for i in range(args.warmup):
+            train_iter(i)
+        par.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            train_iter(args.warmup + i)
+        par.barrier(); torch.cuda.synchronize()
+        dt_tr = par.max_over_ranks(time.perf_counter() - t0, dev)
+        L.fdgs_timing_enable(1)
+        for i in range(4):
+            train_iter(i)
+        buf2 = ctypes.create_string_buffer(1 << 16)
+        fdgs._lib.check(L.fdgs_timing_report(buf2, len(buf2), 1))
+        L.fdgs_timing_enable(0)
+        extra = {}
+        for line in buf2.value.decode().strip().splitlines():
+            name, cnt, tot = line.split()
+            if name in ("plane_regulation", "adam_step"):
+                extra[name] = round(float(tot) / 4, 4)
+        train = {"iterations_per_s": world * args.steps / dt_tr, "ms_per_iteration": dt_tr / args.steps * 1e3,
+                 "includes": "render fwd+bwd, L1 stats, HexPlane regulariser fwd+bwd, FusedAdam step over all 8 parameter groups (lr = 0)",
+                 "extra_kernels_ms_per_iteration": extra}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(fdgs, syn, pc, cams[args.warmup % len(cams)], target, dcfg, args.cpu_frames)
@@ -167,7 +205,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "train_iteration": train,
             "frame_hbm": {"algorithmic_bytes": B_frame, "achieved_GBps": B_frame / (dt / args.steps / 1) / 1e9 if world == 1 else None,
                           "frac_of_8TBps": (B_frame / (dt / args.steps)) / HBM_PEAK if world == 1 else None,
                           "note": "working set < 256 MiB Infinity Cache at this size: the HBM fraction is structurally small"},
