@@ -38,7 +38,7 @@ class DeformParams(Structure):
 
 class DeformOut(Structure):
     _fields_ = [("xyz", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("opacity", c_void_p), ("shs", c_void_p),
-                ("rot_norm", c_void_p)]
+                ("rot_norm", c_void_p), ("saved", c_void_p)]
 
 
 class DeformGrads(Structure):
@@ -47,7 +47,7 @@ class DeformGrads(Structure):
                 ("rot_norm", c_void_p), ("d_xyz", c_void_p), ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p),
                 ("d_shs_dc", c_void_p), ("d_shs_rest", c_void_p), ("d_planes", (c_void_p * 6) * MAX_LEVELS),
                 ("d_w0", c_void_p), ("d_b0", c_void_p), ("d_w1", c_void_p * NUM_HEADS), ("d_b1", c_void_p * NUM_HEADS),
-                ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p)]
+                ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p), ("saved", c_void_p)]
 
 
 class RegPlane(Structure):
@@ -79,6 +79,7 @@ SYMBOLS = {
     "fdgs_geom_field": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "fdgs_binning_field": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, POINTER(c_void_p)]),
     "fdgs_img_field": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "fdgs_deform_saved_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_fwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformOut)]),
     "fdgs_deform_bwd_scratch_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),

@@ -85,6 +85,10 @@ struct DeformDev {
     fdgs_deform_out out;
     int F;
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
+    // optional saved activations for the backward (rows < Npad): features [Np][F], relu(hidden) [Np][W], relu(h1) [slot][Np][W]
+    float *sv_feat, *sv_rh, *sv_h1;
+    int Npad;
+    int head_slot[FDGS_NUM_HEADS];
 };
 
 // 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian.
@@ -355,6 +359,25 @@ __device__ __forceinline__ void store_il(float* __restrict__ rowp, const f32x16*
     }
 }
 
+// [32 gaussians][W] tile of interleaved activations -> 32 contiguous global rows, through a padded per-wave LDS tile:
+// the lanes park "their" Gaussian's row (store_il layout), then the wave copies the 32*W floats out lane-consecutively
+// (1 KB per store instruction).  Direct store_il to global writes 16-byte pieces at 512-byte strides: measured +0.19 ms on
+// the forward for the 960 MB of saved activations.
+template <int T>
+__device__ __forceinline__ void store_tile_coalesced(float* lds_tile, float* __restrict__ gdst, const f32x16* x, int g, int h, int lane) {
+    constexpr int W = 32 * T, STRIDE = W + 4;
+    __builtin_amdgcn_wave_barrier();
+    store_il<T>(lds_tile + g * STRIDE, x, h);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < T * 4; j++) {
+        const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
+        reinterpret_cast<float4*>(gdst)[e4] = *reinterpret_cast<const float4*>(lds_tile + row * STRIDE + 4 * c4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ int next_head(const int* head_on, int hd) {
@@ -372,6 +395,9 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     constexpr int PD1 = FwdPD<WT>::L1, PD2 = FwdPD<WT>::L2;
     const fdgs_deform_params& p = d.p;
     const bool tunable_small = d.small_heads != 0;
+    __shared__ __attribute__((aligned(16))) float fwd_lds[4 * 32 * (WT * 32 + 4)];   // staging tiles of the saved activations
+    float* my_tile = fwd_lds + (threadIdx.x >> 6) * 32 * (WT * 32 + 4);
+    const size_t tile_n0 = (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;       // first Gaussian slot of this wave
     constexpr int FT = (FCH + 3) / 4;
     const int lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
     const int n_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + g;
@@ -406,9 +432,17 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 #pragma unroll
     for (int t = 0; t < FT; t++) feat[t] = zero16();
     gather_features<FCH>(p, q, h, feat);
+    const size_t n_row = (size_t)n_raw;   // saved rows are indexed by the un-clamped Gaussian slot (< Npad)
+    if (d.sv_feat) {
+#pragma unroll
+        for (int j = 0; j < FCH; j++)
+            *reinterpret_cast<float4*>(d.sv_feat + n_row * d.F + 8 * j + 4 * h) =
+                make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
+    }
     f32x16 hid[WT];
     T0.run(feat, hid, h);
     relu_inplace<WT>(hid);  // every consumer of the trunk output starts with ReLU (scene/deformation.py:61-65)
+    if (d.sv_rh) store_tile_coalesced<WT>(my_tile, d.sv_rh + tile_n0 * W, hid, g, h, lane);
 
     const bool writer = live && h == 0;
     // epilogue of head hd applied to the head's output delta (zero for a switched-off head: it returns its input
@@ -473,6 +507,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         f32x16 h1[WT];
         L1.run(hid, h1, h);
         relu_inplace<WT>(h1);
+        if (d.sv_h1) store_tile_coalesced<WT>(my_tile, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W, h1, g, h, lane);
         if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head(p.head_on, hd);
         if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
@@ -625,6 +660,7 @@ struct BwdDev {
     int F;
     int head_slot[FDGS_NUM_HEADS];  // index of the head's dH1 slab
     int ntiles;                     // 32-Gaussian tiles (Npad / 32)
+    const float *sv_rh, *sv_h1;     // SAVED kernels: relu(hidden) [Np][W], relu(h1) [slot][Np][W] written by the forward
     int small_heads;                // 1: dW2 of the k<=4 heads on the 4x4x1 MFMA with register-resident sums (FDGS_SMALL_HEADS)
     unsigned long long* prof;       // development builds (-DFDGS_PROFILE_D2): per-wave cycle sums per phase
 };
@@ -658,7 +694,10 @@ __device__ __forceinline__ void small_dw2_steps(f32x4* acc, float sa0, float sa1
     }
 }
 
-template <int WT, int FCH>
+// SAVED: the forward left features / relu(hidden) / relu(h1) behind (fdgs_deform_out::saved): no gather, no trunk, no
+// recomputation of the heads' hidden layers -- the h1 tile is copied straight from memory into the (already transposed)
+// LDS tile, the ReLU masks are read back from it, and `hid` never occupies registers.
+template <int WT, int FCH, bool SAVED>
 __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     const fdgs_deform_params& p = d.p;
     constexpr int FT = (FCH + 3) / 4;
@@ -704,29 +743,57 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         const int n0 = tile * 32;  // first Gaussian of this wave's tile (rows < Npad always exist in scratch)
         const int n_row = n0 + g;
         const int n = n_row < p.N ? n_row : p.N - 1;
-        DenseTrunk<FCH, WT, 2> T0;
-        T0.setup(p.w0, p.b0, F, g, h);
-        T0.preload();
         int hd = next_head(p.head_on, -1);
         DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
-        L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);   // at least one head is active (checked on the host)
-        L1.preload();
-        float q[4], xyz[3];
-        load_query(p, n, q, xyz);
-        f32x16 feat[FT];
+        f32x16 hid[SAVED ? 1 : WT], dhid[WT];
+        uint32_t hidmask[WT];   // SAVED: bit r of hidmask[t] = relu(hidden)[t][r] > 0
+        if constexpr (!SAVED) {
+            DenseTrunk<FCH, WT, 2> T0;
+            T0.setup(p.w0, p.b0, F, g, h);
+            T0.preload();
+            L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);   // at least one head is active (checked on the host)
+            L1.preload();
+            float q[4], xyz[3];
+            load_query(p, n, q, xyz);
+            f32x16 feat[FT];
 #pragma unroll
-        for (int t = 0; t < FT; t++) feat[t] = zero16();
-        gather_features<FCH>(p, q, h, feat);
+            for (int t = 0; t < FT; t++) feat[t] = zero16();
+            gather_features<FCH>(p, q, h, feat);
 #pragma unroll
-        for (int j = 0; j < FCH; j++)
-            *reinterpret_cast<float4*>(d.s.FEAT + (size_t)n_row * F + 8 * j + 4 * h) =
-                make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
-        f32x16 hid[WT], dhid[WT];
-        D2_TICK(0);
-        T0.run(feat, hid, h);
-        relu_inplace<WT>(hid);
-        store_il<WT>(d.s.RH + (size_t)n_row * W, hid, h);
-        D2_TICK(1);
+            for (int j = 0; j < FCH; j++)
+                *reinterpret_cast<float4*>(d.s.FEAT + (size_t)n_row * F + 8 * j + 4 * h) =
+                    make_float4(feat[j / 4][4 * (j % 4)], feat[j / 4][4 * (j % 4) + 1], feat[j / 4][4 * (j % 4) + 2], feat[j / 4][4 * (j % 4) + 3]);
+            D2_TICK(0);
+            T0.run(feat, hid, h);
+            relu_inplace<WT>(hid);
+            store_il<WT>(d.s.RH + (size_t)n_row * W, hid, h);
+            D2_TICK(1);
+        } else {
+            (void)n;
+            const float* rhp = d.sv_rh + (size_t)n_row * W;
+#pragma unroll
+            for (int t = 0; t < WT; t++) hidmask[t] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const AVec<WT> v = ldv<WT>(rhp + WT * rho(r, h));
+#pragma unroll
+                for (int t = 0; t < WT; t++) hidmask[t] |= (v.v[t] > 0.f ? 1u : 0u) << r;
+            }
+        }
+        // SAVED: the relu(h1) tile of the NEXT head to process is fetched one head ahead (64 registers), under the long
+        // transposed product of the current one -- the kernel is otherwise HBM-latency bound on these 16-KB tiles
+        // (sixteen named registers quadruples, not an array: an array carried across the head loop is "promoted" to LDS by
+        // the compiler's alloca pass instead of being scalarised)
+#define FDGS_TV_LIST(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
+#define FDGS_TV_DECL(j) float4 tv##j = make_float4(0.f, 0.f, 0.f, 0.f);
+        FDGS_TV_LIST(FDGS_TV_DECL)
+#define FDGS_TV_LOAD(j) if (j < WT * 4) tv##j = tsrc[j * 64 + lane];
+#define FDGS_TV_STORE(j) if (j < WT * 4) { const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4); \
+                                          *reinterpret_cast<float4*>(lds + row * STRIDE + 4 * c4) = tv##j; }
+        if constexpr (SAVED) {
+            const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[hd] * d.s.Npad + n0) * W);
+            FDGS_TV_LIST(FDGS_TV_LOAD)
+        }
 #pragma unroll
         for (int t = 0; t < WT; t++) dhid[t] = zero16();
         const float* Grow = d.s.G + (size_t)n_row * GCOLS;
@@ -759,7 +826,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #pragma unroll
                 for (int s = 0; s < 16; s++) ga[s] = 0.f;
             }
-            {
+            if constexpr (!SAVED) {
                 f32x16 h1[WT];
                 L1.run(hid, h1, h);
                 D2_TICK(2);
@@ -775,9 +842,23 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 // transposed copy relu(h1)[gaussian][feature] for the dW2 product
                 if (tiles_shared) { __syncthreads(); tiles_shared = false; }
                 store_il<WT>(lds + g * STRIDE, h1, h);
+            } else {
+                // the saved relu(h1) rows of this tile are 32 x W contiguous floats: copy them, lane-consecutive, into the
+                // padded LDS tile [gaussian][W + 4]; then every lane reads its own Gaussian's row back for the ReLU mask
+                if (tiles_shared) { __syncthreads(); tiles_shared = false; }
+                FDGS_TV_LIST(FDGS_TV_STORE)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < WT; t++) mask[t] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const AVec<WT> v = ldv<WT>(lds + g * STRIDE + WT * rho(r, h));
+#pragma unroll
+                    for (int t = 0; t < WT; t++) mask[t] |= (v.v[t] > 0.f ? 1u : 0u) << r;
+                }
+                D2_TICK(2);
             }
-            // ... the first operands of the long transposed product, and of dh1 = W2^T G_head (k-steps over the head's
-            // outputs, two per MFMA: A = W2 row o, B = G[gaussian][o])
             DenseT<WT, WT, true, 4> B1;
             const float* w2p = p.w2[hd] + WT * g;
             const int nsteps = (k + 1) >> 1;
@@ -907,14 +988,26 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             for (int t = 0; t < WT; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) dh1[t][r] = ((mask[t] >> r) & 1u) ? dh1[t][r] : 0.f;
-            store_il<WT>(slab + (size_t)n_row * W, dh1, h);
+            // through the (now idle) LDS tile when no other wave can still be reading it: 32 contiguous rows, 1 KB per store
+            if (!tiles_shared) store_tile_coalesced<WT>(lds, slab + (size_t)n0 * W, dh1, g, h, lane);
+            else store_il<WT>(slab + (size_t)n_row * W, dh1, h);
             D2_TICK(6);
+            if constexpr (SAVED) {
+                const int nx = next_head(p.head_on, hd);
+                if (nx < FDGS_NUM_HEADS) {
+                    const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[nx] * d.s.Npad + n0) * W);
+                    FDGS_TV_LIST(FDGS_TV_LOAD)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- dhid += W1^T dh1
             B1.run(dh1, dhid);
             __builtin_amdgcn_wave_barrier();
             D2_TICK(7);
             hd = next_head(p.head_on, hd);
-            if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
+            if constexpr (!SAVED) {
+                if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
+            }
         }
         // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
         DenseT<WT, FT, false, 4> B0;
@@ -923,7 +1016,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #pragma unroll
         for (int t = 0; t < WT; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) dhid[t][r] = hid[t][r] > 0.f ? dhid[t][r] : 0.f;
+            for (int r = 0; r < 16; r++) {
+                bool pos;
+                if constexpr (SAVED) pos = (hidmask[t] >> r) & 1u; else pos = hid[t][r] > 0.f;
+                dhid[t][r] = pos ? dhid[t][r] : 0.f;
+            }
         store_il<WT>(d.s.DHID + (size_t)n_row * W, dhid, h);
         f32x16 dfeat[FT];
 #pragma unroll
@@ -1290,23 +1387,28 @@ struct FwdLauncher {
         hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
+template <int WT, int FCH, bool SAVED>
+static void launch_bwd_data(hipStream_t s, int max_blocks, const BwdDev& d) {
+    // persistent: as many workgroups as are co-resident (each keeps dW2/db2 sums in LDS), tiles handed out round-robin
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, cus = 256, per_cu = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, deform_bwd_data_kernel<WT, FCH, SAVED>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = cus * per_cu;
+    }
+    int blocks = tunable("FDGS_D2_WGS", resident);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((deform_bwd_data_kernel<WT, FCH, SAVED>), dim3(blocks), dim3(256), 0, s, d);
+}
 template <int WT, int FCH>
 struct BwdLauncher {
-    // persistent: as many workgroups as are co-resident (each keeps dW2/db2 sums in LDS), tiles handed out round-robin
     static void go(hipStream_t s, int max_blocks, const BwdDev& d) {
-        static int resident = 0;
-        if (resident == 0) {
-            int dev = 0, cus = 256, per_cu = 1;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, deform_bwd_data_kernel<WT, FCH>, 256, 0) != hipSuccess || per_cu < 1)
-                per_cu = 1;
-            resident = cus * per_cu;
-        }
-        int blocks = tunable("FDGS_D2_WGS", resident);
-        if (blocks > max_blocks) blocks = max_blocks;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL((deform_bwd_data_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
+        if (d.sv_h1) launch_bwd_data<WT, FCH, true>(s, max_blocks, d);
+        else launch_bwd_data<WT, FCH, false>(s, max_blocks, d);
     }
 };
 
@@ -1315,6 +1417,16 @@ static int active_heads(const fdgs_deform_params* p) {
     int c = 0;
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) c += p->head_on[hd] ? 1 : 0;
     return c;
+}
+// activations the forward can leave behind for the backward (float offsets into the `saved` buffer)
+struct SavedLayout { size_t Np, feat, rh, h1, floats; };
+static SavedLayout saved_layout(const fdgs_deform_params* p) {
+    SavedLayout s;
+    s.Np = npad_of(p->N);
+    const size_t F = (size_t)p->C * p->L, W = p->W;
+    s.feat = 0; s.rh = s.feat + s.Np * F; s.h1 = s.rh + s.Np * W;
+    s.floats = s.h1 + s.Np * W * active_heads(p);
+    return s;
 }
 
 }  // namespace fdgs
@@ -1330,11 +1442,27 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     DeformDev d;
     d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1);
     {
+        const SavedLayout sl = saved_layout(p);
+        float* sv = reinterpret_cast<float*>(out->saved);
+        d.sv_feat = sv ? sv + sl.feat : nullptr; d.sv_rh = sv ? sv + sl.rh : nullptr; d.sv_h1 = sv ? sv + sl.h1 : nullptr;
+        d.Npad = (int)sl.Np;
+        int slot = 0;
+        for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) d.head_slot[hd] = p->head_on[hd] ? slot++ : 0;
+    }
+    {
         FDGS_TIMED("deform_fwd", stream);
         rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, cdiv(p->N, 128), d);
     }
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_fwd", 0, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_deform_saved_bytes(const fdgs_deform_params* p, size_t* bytes) {
+    int rc = validate_deform(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(bytes, "bytes is NULL");
+    *bytes = saved_layout(p).floats * sizeof(float) + 256;
     return FDGS_OK;
 }
 
@@ -1384,6 +1512,15 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
     BwdDev bd;
     bd.p = *p; bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
+    const float* X_rh = s.RH;      // operands of the weight-gradient GEMMs: recomputed into scratch, or saved by the forward
+    const float* X_feat = s.FEAT;
+    bd.sv_rh = bd.sv_h1 = nullptr;
+    if (g->saved && tunable("FDGS_USE_SAVED", 1)) {
+        const SavedLayout sl = saved_layout(p);
+        const float* sv = reinterpret_cast<const float*>(g->saved);
+        bd.sv_rh = sv + sl.rh; bd.sv_h1 = sv + sl.h1;
+        X_rh = sv + sl.rh; X_feat = sv + sl.feat;
+    }
     int slot = 0;
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
         bd.d_w2[hd] = g->d_w2[hd]; bd.d_b2[hd] = g->d_b2[hd];
@@ -1430,12 +1567,12 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
         if (!p->head_on[hd]) continue;
         WgradJob& J = wa.job[nj++];
-        J.DY = s.DH1 + (size_t)bd.head_slot[hd] * Np * W; J.X = s.RH; J.dW = g->d_w1[hd]; J.db = g->d_b1[hd];
+        J.DY = s.DH1 + (size_t)bd.head_slot[hd] * Np * W; J.X = X_rh; J.dW = g->d_w1[hd]; J.db = g->d_b1[hd];
         J.ldx = (int)W; J.ncols = (int)W; J.ldw = (int)W;
     }
     {
         WgradJob& J = wa.job[nj++];
-        J.DY = s.DHID; J.X = s.FEAT; J.dW = g->d_w0; J.db = g->d_b0; J.ldx = (int)F; J.ncols = (int)F; J.ldw = (int)F;
+        J.DY = s.DHID; J.X = X_feat; J.dW = g->d_w0; J.db = g->d_b0; J.ldx = (int)F; J.ncols = (int)F; J.ldw = (int)F;
     }
     wa.njobs = nj;
     {

@@ -13,12 +13,18 @@ Unsupported reference options raise instead of silently running something else: 
 empty_voxel, apply_rotation, defor_depth > 1 (none is enabled by any config under arguments/ of the reference).
 """
 import itertools
+import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib
 from ._lib import MAX_LEVELS, NUM_HEADS, DeformGrads, DeformOut, DeformParams, check, ptr, stream_ptr
+
+# Training-time trade: when a backward will follow, the forward also stores the HexPlane features, relu(hidden) and
+# relu(h1) of every active head (~3.2 KB per Gaussian at net_width 128 with five heads) so that the backward skips the
+# gather and the recomputation of those layers.  False = recompute everything (no extra memory).
+SAVE_ACTIVATIONS = os.environ.get("FDGS_SAVE_ACTIVATIONS", "1") != "0"
 
 HEAD_NAMES = ("pos_deform", "scales_deform", "rotations_deform", "opacity_deform", "shs_deform")
 HEAD_FLAGS = ("no_dx", "no_ds", "no_dr", "no_do", "no_dshs")
@@ -219,18 +225,20 @@ def _fill_params(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
     return p
 
 
-_aabb_cache = {}
+_aabb_cache = [None, None, None]   # (weakref to the tensor object, its version counter, host floats)
 
 
 def _aabb_to_host(aabb):
-    """The 6 aabb floats are needed in the kernel-argument struct; cache the host copy per tensor version."""
-    key = (aabb.data_ptr(), aabb._version)
-    v = _aabb_cache.get(key)
-    if v is None:
-        v = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
-        _aabb_cache.clear()
-        _aabb_cache[key] = v
-    return v
+    """The 6 aabb floats are needed in the kernel-argument struct; cache the host copy per tensor OBJECT and version.
+    (Keying on data_ptr() is wrong: the caching allocator hands a freed aabb's address to the next model's aabb.)"""
+    import weakref
+    ref, ver, vals = _aabb_cache
+    key = (aabb._version, aabb.data_ptr())
+    if ref is not None and ref() is aabb and ver == key:
+        return vals
+    vals = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
+    _aabb_cache[0], _aabb_cache[1], _aabb_cache[2] = weakref.ref(aabb), key, vals
+    return vals
 
 
 class _DeformFunction(torch.autograd.Function):
@@ -257,6 +265,13 @@ class _DeformFunction(torch.autograd.Function):
         o_sh = torch.empty(N, 16, 3, device=dev)
         o_norm = torch.empty(N, device=dev) if cfg["activate"] else None
         out.xyz, out.scales, out.rotations, out.opacity, out.shs, out.rot_norm = ptr(o_xyz), ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_sh), ptr(o_norm)
+        saved = None
+        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):
+            nbytes = _lib.c_size_t()
+            check(L.fdgs_deform_saved_bytes(p, nbytes))
+            saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out.saved = ptr(saved)
+        ctx.saved_act = saved
         check(L.fdgs_deform_fwd(stream_ptr(), p, out))
         ctx.cfg, ctx.t_scalar, ctx.p, ctx.keep = cfg, t_scalar, p, keep
         ctx.saved = (o_sc, o_rot, o_op, o_norm)
@@ -313,6 +328,7 @@ class _DeformFunction(torch.autograd.Function):
         check(L.fdgs_deform_bwd_scratch_bytes(p, nbytes))
         scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         g.scratch = ptr(scratch)
+        g.saved = ptr(ctx.saved_act)
         check(L.fdgs_deform_bwd(stream_ptr(), p, g))
         for h in range(NUM_HEADS):  # parameters of a disabled head receive no gradient (as under autograd)
             if not cfg["head_on"][h]:

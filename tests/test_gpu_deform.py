@@ -66,6 +66,14 @@ def test_deform_parity_one_frame_time(cfg, n, t):
     _parity(cfg, n, True, scalar_time=t)
 
 
+@pytest.mark.parametrize("cfg,n", [("dynerf_default", 1200), ("hypernerf_default", 300)])
+def test_deform_parity_recompute_path(cfg, n, monkeypatch):
+    """The backward without saved activations (fdgs_deform_out::saved = NULL): gather, trunk and the heads' hidden layers
+    are recomputed inside the backward kernel."""
+    monkeypatch.setattr(_fdgs().deformation, "SAVE_ACTIVATIONS", False)
+    _parity(cfg, n, True)
+
+
 def _parity(cfg, n, activate, scalar_time=None):
     dev = torch.device("cuda:0")
     fd = _fdgs()
@@ -137,6 +145,23 @@ def test_deform_unfiltered_inputs_loose(cfg, n):
     for a, b in zip(g_gpu, g_ref):
         if b is not None:
             assert rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape)) < 2e-2
+
+
+def test_aabb_host_copy_is_keyed_on_the_tensor_object_not_its_address():
+    """Regression: the host copy of the aabb used to be cached by data_ptr(); the caching allocator hands a freed model's
+    aabb address to the next model, which then silently ran with the previous model's bounds."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    outs = []
+    for bounds in ([1.3, 1.25, 1.2], [2.0, 2.5, 3.0]):
+        args, net, ins = _net_and_inputs("dynerf_default", 64, 5, dev, safe=False)
+        net = net.to(dev)
+        net.deformation_net.set_aabb(bounds, [-b for b in bounds])
+        gi = [x.to(dev) for x in ins]
+        outs.append(fd.deformation.deform(net, gi[0], gi[1], gi[2], gi[3], shs=gi[4], time=0.5, activate=False)[0].cpu())
+        del net
+        torch.cuda.empty_cache()
+    assert float((outs[0] - outs[1]).abs().max()) > 1e-4     # different bounds -> different HexPlane lookups
 
 
 def test_module_api_matches_reference_signature_and_scalar_time():
