@@ -235,7 +235,11 @@ struct DenseIL {
         }
         return out;
     }
-    __device__ __forceinline__ void run(const f32x16* X, f32x16* Y, int h) {
+    struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+    __device__ __forceinline__ void run(const f32x16* X, f32x16* Y, int h) { run(X, Y, h, NoHook()); }
+    // `hook(s)` is issued once per k-walk step, in the shadow of that step's MFMAs (used to drain a staged tile)
+    template <class Hook>
+    __device__ __forceinline__ void run(const f32x16* X, f32x16* Y, int h, Hook hook) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) Y[ot] = mfma32(h == 0 ? bv[ot] : 0.f, 1.0f, zero16());
 #pragma unroll
@@ -244,6 +248,7 @@ struct DenseIL {
 #pragma unroll
             for (int ot = 0; ot < OT; ot++) cur[ot] = buf[s % PD][ot];
             if (s + PD < 16) fetch(s + PD, buf[s % PD]);
+            hook(s);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PD steps ahead (the scheduler sinks it to its use otherwise)
 #pragma unroll
             for (int t = 0; t < KT; t++)
@@ -442,7 +447,21 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     f32x16 hid[WT];
     T0.run(feat, hid, h);
     relu_inplace<WT>(hid);  // every consumer of the trunk output starts with ReLU (scene/deformation.py:61-65)
-    if (d.sv_rh) store_tile_coalesced<WT>(my_tile, d.sv_rh + tile_n0 * W, hid, g, h, lane);
+    // saved activations leave through the LDS tile: parked right after they are computed, copied out (lane-consecutive,
+    // 1 KB per store) one 1-KB piece per k-walk step of the NEXT hidden layer, i.e. in the shadow of its MFMAs
+    float* pending_dst = nullptr;
+    constexpr int TSTRIDE = WT * 32 + 4;
+    auto park = [&](const f32x16* x, float* dst) {
+        store_il<WT>(my_tile + g * TSTRIDE, x, h);
+        pending_dst = dst;
+    };
+    auto drain_piece = [&](int j) {     // pieces j = 0 .. 4*WT-1 of 64 float4 each
+        if (pending_dst && j < WT * 4) {
+            const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
+            reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
+        }
+    };
+    if (d.sv_rh) park(hid, d.sv_rh + tile_n0 * W);
 
     const bool writer = live && h == 0;
     // epilogue of head hd applied to the head's output delta (zero for a switched-off head: it returns its input
@@ -505,9 +524,9 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         else L2.setup(p.w2[hd], p.b2[hd], W, k < 32 ? k : 32, g, h);
         L2.preload();
         f32x16 h1[WT];
-        L1.run(hid, h1, h);
+        L1.run(hid, h1, h, drain_piece);
         relu_inplace<WT>(h1);
-        if (d.sv_h1) store_tile_coalesced<WT>(my_tile, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W, h1, g, h, lane);
+        if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
         if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head(p.head_on, hd);
         if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
@@ -522,6 +541,9 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         epilogue(hd, o0, o1);
         hd = nxt;
     }
+    // the last parked tile has no following layer to hide under
+#pragma unroll
+    for (int j = 0; j < WT * 4; j++) drain_piece(j);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: prep
@@ -974,13 +996,33 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             f32x16 dh1[WT];
 #pragma unroll
             for (int t = 0; t < WT; t++) dh1[t] = zero16();
-            for (int s = 0; s < nsteps; s++) {
-                const AVec<WT> a = a0;
-                const float b = b0;
-                a0 = a1; b0 = b1; a1 = a2; b1 = b2;
-                if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
+            if (k > 32) {
+                // the 48-output head: 24 k-steps, fully unrolled with a 6-deep operand ring (a 3-deep rotating ring left the
+                // MFMAs waiting on L2 for most steps: 12 % of the kernel in the cycle profile)
+                constexpr int PDH = 6, NSH = 24;
+                AVec<WT> ra[PDH];
+                float rb[PDH];
+                ra[0] = a0; ra[1] = a1; ra[2] = a2; rb[0] = b0; rb[1] = b1; rb[2] = b2;
 #pragma unroll
-                for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
+                for (int s = 3; s < PDH; s++) { ra[s] = ldA(s); rb[s] = ldB(s); }
+#pragma unroll
+                for (int s = 0; s < NSH; s++) {
+                    const AVec<WT> a = ra[s % PDH];
+                    const float b = rb[s % PDH];
+                    if (s + PDH < NSH) { ra[s % PDH] = ldA(s + PDH); rb[s % PDH] = ldB(s + PDH); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
+                }
+            } else {
+                for (int s = 0; s < nsteps; s++) {
+                    const AVec<WT> a = a0;
+                    const float b = b0;
+                    a0 = a1; b0 = b1; a1 = a2; b1 = b2;
+                    if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
+#pragma unroll
+                    for (int t = 0; t < WT; t++) dh1[t] = mfma32(a.v[t], b, dh1[t]);
+                }
             }
             D2_TICK(5);
             float* slab = d.s.DH1 + (size_t)d.head_slot[hd] * d.s.Npad * W;
@@ -1010,7 +1052,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             }
         }
         // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
-        DenseT<WT, FT, false, 4> B0;
+        DenseT<WT, FT, false, 16> B0;   // one dword per k-step and only FT MFMAs behind it: a deep ring hides the L2 latency
         B0.setup(p.w0, F, F, g, h);
         B0.preload();
 #pragma unroll
