@@ -274,7 +274,11 @@ class _DeformFunction(torch.autograd.Function):
         ctx.saved_act = saved
         check(L.fdgs_deform_fwd(stream_ptr(), p, out))
         ctx.cfg, ctx.t_scalar, ctx.p, ctx.keep = cfg, t_scalar, p, keep
-        ctx.saved = (o_sc, o_rot, o_op, o_norm)
+        # outputs the backward needs go through save_for_backward: keeping them as plain attributes makes a reference
+        # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC breaks -- with ~1 GB of per-frame buffers
+        # hanging on it (saved activations) every frame then costs a fresh 1-GB hipMalloc (30 ms)
+        ctx.save_for_backward(o_sc, o_rot, o_op)
+        ctx.o_norm = o_norm
         ctx.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape,
                           sh_b=None if sh_b is None else sh_b.shape)
         ctx.plane_shapes = [tuple(q.shape) for q in planes_in]
@@ -286,7 +290,8 @@ class _DeformFunction(torch.autograd.Function):
         L = _lib.lib()
         cfg, p = ctx.cfg, ctx.p
         xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, planes, mlp = ctx.keep[0]
-        o_sc, o_rot, o_op, o_norm = ctx.saved
+        o_sc, o_rot, o_op = ctx.saved_tensors
+        o_norm = ctx.o_norm
         dev, N = xyz.device, xyz.shape[0]
         c = lambda t: None if t is None else t.float().contiguous()
         g = DeformGrads()
