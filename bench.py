@@ -137,7 +137,15 @@ def main():
     ms_step = dt / args.steps * 1e3
     # dominant kernel and its roofline
     dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
-    mfma_flops = {"deform_fwd": flops_fwd, "deform_bwd_data": 2 * flops_fwd, "deform_wgrad": flops_fwd}
+    # backward-data FLOPs: with saved activations (default) the kernel only does the backward products proper --
+    # dh1 = W2^T G (2 W k), dW2 = G^T h1 (2 W k), dhid += W1^T dh1 (2 W^2) per head, dfeat = W0^T dhid (2 F W);
+    # without them it also recomputes the forward (trunk + the heads' hidden layers)
+    Fd, Wd = cfg["kplanes_config"]["output_coordinate_dim"] * len(cfg["multires"]), cfg["net_width"]
+    ks_on = [k for k, off in zip((3, 3, 4, 1, 48), (cfg["no_dx"], cfg["no_ds"], cfg["no_dr"], cfg["no_do"], cfg["no_dshs"])) if not off]
+    bwd_core = N * (sum(2 * Wd * Wd + 4 * Wd * k for k in ks_on) + 2 * Fd * Wd)
+    recompute = N * (2 * Fd * Wd + sum(2 * Wd * Wd for _ in ks_on))
+    saved_on = bool(fdgs.deformation.SAVE_ACTIVATIONS)
+    mfma_flops = {"deform_fwd": flops_fwd, "deform_bwd_data": bwd_core if saved_on else bwd_core + recompute, "deform_wgrad": flops_fwd}
     hbm_bytes = {"render_bwd": stage_bytes["render_bwd"], "render_fwd": stage_bytes["render_fwd"],
                  "preprocess_fwd": stage_bytes["preprocess_fwd"], "preprocess_bwd": stage_bytes["preprocess_bwd"],
                  "deform_plane_grad": N * 12 + N * (cfg["kplanes_config"]["output_coordinate_dim"] * len(cfg["multires"])) * 4 + 2 * G,
@@ -149,7 +157,9 @@ def main():
         if dom in mfma_flops:
             a = mfma_flops[dom] / lps / t_dom
             roof = dict(kernel=dom, bound="mfma", achieved=a / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
-                        frac=a / MFMA_F32_PEAK, traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps)
+                        frac=a / MFMA_F32_PEAK, traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps,
+                        algorithmic_flops_per_launch=mfma_flops[dom] / lps,
+                        note=("saved activations: backward products only" if dom == "deform_bwd_data" and saved_on else None))
         else:
             a = hbm_bytes.get(dom, 0) / lps / t_dom
             roof = dict(kernel=dom, bound="hbm", achieved=a / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=a / HBM_PEAK,
