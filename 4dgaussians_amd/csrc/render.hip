@@ -124,6 +124,10 @@ struct RenderBwdArgs {
 
 constexpr int ACC_STRIDE = 257;  // 10 rows of 256 sums, odd row stride => conflict-free LDS atomics and flush
 
+// DEPTH: a gradient w.r.t. the depth image was handed in (dL_ddepth != NULL).  The reference's training loss never uses it
+// (utils/scene_utils.py:29 reads depth under no_grad), so the common instantiation drops the depth accumulators, their
+// row reduction and the tenth LDS column.
+template <bool DEPTH>
 __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f;
     if (inside) {
         dp0 = a.dL_dcolor[pix]; dp1 = a.dL_dcolor[hw + pix]; dp2 = a.dL_dcolor[2 * hw + pix];
-        if (a.dL_ddepth) ddep = a.dL_ddepth[pix];
+        if (DEPTH) ddep = a.dL_ddepth[pix];
     }
     const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
     float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
@@ -193,9 +197,13 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
                 acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = Cc.x;
                 acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = Cc.y;
                 acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = Cc.z;
-                accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = B.z;
-                dL_dalpha = (Cc.x - acc0) * dp0 + (Cc.y - acc1) * dp1 + (Cc.z - acc2) * dp2 + (B.z - accd) * ddep;
-                g_c0 = w * dp0; g_c1 = w * dp1; g_c2 = w * dp2; g_d = w * ddep;
+                dL_dalpha = (Cc.x - acc0) * dp0 + (Cc.y - acc1) * dp1 + (Cc.z - acc2) * dp2;
+                if (DEPTH) {
+                    accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = B.z;
+                    dL_dalpha += (B.z - accd) * ddep;
+                    g_d = w * ddep;
+                }
+                g_c0 = w * dp0; g_c1 = w * dp1; g_c2 = w * dp2;
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final * inv) * bgdot;
@@ -214,13 +222,13 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
             g_cxx = row_allsum(g_cxx); g_cxy = row_allsum(g_cxy); g_cyy = row_allsum(g_cyy);
             g_op = row_allsum(g_op);
             g_c0 = row_allsum(g_c0); g_c1 = row_allsum(g_c1); g_c2 = row_allsum(g_c2);
-            g_d = row_allsum(g_d);
+            if (DEPTH) g_d = row_allsum(g_d);
             const int sub = lane & 15;
             float v = g_mx;
             v = sub == 1 ? g_my : v; v = sub == 2 ? g_cxx : v; v = sub == 3 ? g_cxy : v; v = sub == 4 ? g_cyy : v;
             v = sub == 5 ? g_op : v; v = sub == 6 ? g_c0 : v; v = sub == 7 ? g_c1 : v; v = sub == 8 ? g_c2 : v;
-            v = sub == 9 ? g_d : v;
-            if (sub < 10) atomicAdd(&sAcc[sub * ACC_STRIDE + j], v);
+            if (DEPTH) v = sub == 9 ? g_d : v;
+            if (sub < (DEPTH ? 10 : 9)) atomicAdd(&sAcc[sub * ACC_STRIDE + j], v);
         }
         __syncthreads();
         // flush: 16 lanes own the 16-float gradient line of one staged Gaussian, so every atomic instruction covers four
@@ -299,7 +307,11 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
         a.gacc = g->scratch_acc;
         const int ntiles = il.gx * il.gy;
-        { FDGS_TIMED("render_bwd", stream); hipLaunchKernelGGL(render_bwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a); }
+        {
+            FDGS_TIMED("render_bwd", stream);
+            if (g->dL_ddepth) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+        }
         FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);
     }
     return fdgs_launch_preprocess_bwd(stream, p, geom, g);
