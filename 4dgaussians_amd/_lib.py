@@ -86,6 +86,7 @@ SYMBOLS = {
     "fdgs_l1_stats": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "fdgs_plane_regulation": (c_int, [c_void_p, c_int, POINTER(RegPlane), c_float, c_void_p, c_void_p]),
     "fdgs_adam_step": (c_int, [c_void_p, c_int, POINTER(AdamTensor), c_double, c_double, c_double]),
+    "fdgs_knn3_mean_dist2": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

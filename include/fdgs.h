@@ -248,6 +248,13 @@ typedef struct fdgs_adam_tensor {
 int fdgs_adam_step(void* stream, int ntensors, const fdgs_adam_tensor* tensors /* host array */, double beta1, double beta2,
                    double eps);   /* doubles: 1 - beta and the bias corrections are formed in double like torch does */
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Scale initialisation: replaces simple_knn._C.distCUDA2 (un-vendored submodule submodules/simple-knn, .gitmodules:1-3;
+ * call site scene/gaussian_model.py:148).  mean_dist2[i] = mean of the three smallest squared distances from point i
+ * to the other points (self excluded by index).  points [N,3], mean_dist2 [N], device.
+ * ---------------------------------------------------------------------------------------------------------- */
+int fdgs_knn3_mean_dist2(void* stream, int N, const float* points, float* mean_dist2);
+
 #ifdef __cplusplus
 }
 #endif
