@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfdgs.so")
+LIB_PATH = os.environ.get("FDGS_LIB") or os.path.join(HERE, "libfdgs.so")   # FDGS_LIB: A/B a development build
 MAX_LEVELS, NUM_HEADS = 4, 5
 
 

@@ -392,12 +392,15 @@ __device__ __forceinline__ int next_head(const int* head_on, int hd) {
 }
 
 // ------------------------------------------------------------------------------------------------ D1 forward
+#ifndef FDGS_D1_PD1
+#define FDGS_D1_PD1 2
+#endif
 template <int WT>
 struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
 
 template <int WT, int FCH>
 __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
-    constexpr int PD1 = FwdPD<WT>::L1, PD2 = FwdPD<WT>::L2;
+    constexpr int PD1 = WT == 4 ? FDGS_D1_PD1 : FwdPD<WT>::L1, PD2 = FwdPD<WT>::L2;
     const fdgs_deform_params& p = d.p;
     const bool tunable_small = d.small_heads != 0;
     __shared__ __attribute__((aligned(16))) float fwd_lds[4 * 32 * (WT * 32 + 4)];   // staging tiles of the saved activations
