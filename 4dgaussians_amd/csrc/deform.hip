@@ -11,15 +11,22 @@
 //     activations are the B operand;
 //   * the MFMA C/D layout puts row (reg&3)+8*(reg>>2)+4*h of column g into lane (g,h) register reg -- which is
 //     exactly the B-operand layout of the NEXT layer if its k-steps are walked in that row order.  So activations
-//     never leave registers between layers: no LDS, no barriers in the forward kernel.
-//   D1 forward: gather features (channel-last planes, one float4 = 4 channels per corner), trunk, heads, epilogue.
-//   D2 backward-data: recompute trunk + head hidden layers, back-propagate through the heads with the transposed
-//      weight walk, write dH1 / dHidden / relu(hidden) / features for the weight-gradient GEMM, dW2 in-kernel (the
-//      only place that needs a transpose, done through a padded per-wave LDS tile).
-//   D3 weight gradients: dW = dY^T X with K = #Gaussians; both MFMA operands are read straight from HBM with 128-B
-//      coalesced rows, split-K over workgroups, one coalesced atomic flush per workgroup.
-//   D4 plane gradients: lanes <-> (x-corner, channel) so that every float atomic instruction covers whole 128-B lines
-//      (scattered float atomics run at only ~20 G line-ops/s on MI355X: profiles/r01_atomic_microbench.txt).
+//     never leave registers between layers (hidden layers use the "interleaved" tile layout described at the MFMA
+//     layer helpers below, which makes W X and W^T dY both read the weights with 16-byte loads).
+//   D1 forward: gather features (channel-last planes, one float4 = 4 channels per corner), trunk, heads (k <= 4 outputs on
+//      the 4x4x1 MFMA), epilogue; optionally parks features / relu(hidden) / relu(h1) for the backward ("saved").
+//   D2 backward-data (persistent, one workgroup per CU): per 32-Gaussian tile and head -- the relu(h1) tile (copied from
+//      the saved activations, or recomputed), dW2/db2 (register sums for the k <= 4 heads, column ownership over the
+//      workgroup's four tiles for the 48-row SH head), dh1 = W2^T G, dhid += W1^T dh1; then dfeat = W0^T dhid.  Writes
+//      dH1 / dHidden (/ relu(hidden) / features when recomputing) for the weight-gradient GEMM.
+//   D3 weight gradients: dW = dY^T X with K = #Gaussians; one wave owns a whole [W x W] product for its slice, one 16-byte
+//      load per operand per 16 MFMAs, LDS reduction over the workgroup, one coalesced atomic flush per workgroup.
+//   D4 plane gradients: lanes <-> (x-corner, channel) so that every float atomic instruction covers whole texel lines
+//      (scattered float atomics run at only ~20 G line-ops/s on MI355X: profiles/r01_atomic_microbench.txt); the three
+//      time planes are privatised in LDS.
+// Environment knobs (development / A-B only, defaults are the tuned values): FDGS_SMALL_HEADS, FDGS_USE_SAVED,
+// FDGS_D2_WGS, FDGS_WGRAD_WGS, FDGS_WGRAD_TRUNK, FDGS_PG_LDS, FDGS_PG_LDS_KB, FDGS_PG_WGS; -DFDGS_PROFILE_D2 adds an
+// in-kernel s_memtime phase profile of D2; -DFDGS_DEV_ONLY_44 builds only the (128, 32) instance.
 #include "common.h"
 
 #include <vector>
