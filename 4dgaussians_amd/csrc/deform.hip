@@ -1273,6 +1273,7 @@ struct PlaneGradArgs {
     int lds_off[FDGS_MAX_LEVELS][3];  // float offset of the LDS tile of time plane k = 2,4,5 (axis a = 0,1,2); -1: global atomics
     int lds_floats;
     int per_block;                    // Gaussians per workgroup
+    int dev_skip_global_atomics;      // development probe (FDGS_PG_NOATOM): measure the kernel without its global atomics
 };
 constexpr int PG_THREADS = 512;
 __host__ __device__ __forceinline__ int time_plane_slot(int k) { return k == 2 ? 0 : (k == 4 ? 1 : (k == 5 ? 2 : -1)); }
@@ -1343,7 +1344,7 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
                 if (dP && live) {
                     if (loff >= 0) {
                         atomicAdd(&lds[loff + oX[k]], dv * wX[k]);   // ds_add_f32
-                    } else {
+                    } else if (!a.dev_skip_global_atomics) {
                         atomicAdd(&dP[oA[k]], dv * wA[k]);
                         atomicAdd(&dP[oB[k]], dv * wB[k]);
                     }
@@ -1687,6 +1688,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             }
         }
         ga.lds_floats = used;
+        ga.dev_skip_global_atomics = tunable("FDGS_PG_NOATOM", 0);
         const int gpb = (PG_THREADS / 64) * (64 / (2 * p->C));       // Gaussians per workgroup iteration
         int nwg = tunable("FDGS_PG_WGS", 512);                        // ~2 workgroups per CU
         int per_block = cdiv(p->N, nwg);
