@@ -87,9 +87,18 @@ __device__ __forceinline__ void plane_axes(int k, int& a, int& b) {
     b = k < 3 ? k + 1 : (k < 5 ? k - 1 : 3);
 }
 
+// inv2[i] = 2 / (aabb[3+i] - aabb[i]), the same float division the reference performs, done once on the host (three
+// full-precision divisions per lane are ~36 VALU instructions)
+struct AabbScale { float inv2[3]; };
+static AabbScale aabb_scale(const fdgs_deform_params* p) {
+    AabbScale s;
+    for (int i = 0; i < 3; i++) s.inv2[i] = 2.0f / (p->aabb[3 + i] - p->aabb[i]);
+    return s;
+}
 struct DeformDev {
     fdgs_deform_params p;
     fdgs_deform_out out;
+    AabbScale sc;
     int F;
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
     // optional saved activations for the backward (rows < Npad): features [Np][F], relu(hidden) [Np][W], relu(h1) [slot][Np][W]
@@ -127,10 +136,10 @@ __device__ __forceinline__ float4 gather_chunk(const fdgs_deform_params& p, int 
     return prod;
 }
 
-__device__ __forceinline__ void load_query(const fdgs_deform_params& p, int n, float* q, float* xyz) {
+__device__ __forceinline__ void load_query(const fdgs_deform_params& p, const AabbScale& sc, int n, float* q, float* xyz) {
     xyz[0] = p.xyz[3 * (size_t)n]; xyz[1] = p.xyz[3 * (size_t)n + 1]; xyz[2] = p.xyz[3 * (size_t)n + 2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) q[i] = (xyz[i] - p.aabb[i]) * (2.0f / (p.aabb[3 + i] - p.aabb[i])) - 1.0f;
+    for (int i = 0; i < 3; i++) q[i] = (xyz[i] - p.aabb[i]) * sc.inv2[i] - 1.0f;
     q[3] = p.time ? p.time[n] : p.time_scalar;
 }
 
@@ -426,7 +435,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     DenseIL<WT, WT, true, PD1, false> L1;
     if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
-    load_query(p, n, q, xyz);
+    load_query(p, d.sc, n, q, xyz);
     // every per-Gaussian input of the epilogues is fetched now (one HBM round trip under the gather) instead of once per
     // head behind its last MFMA
     float in_sc[3], in_op, in_sh[24];
@@ -686,6 +695,7 @@ struct BwdScratch {
 };
 struct BwdDev {
     fdgs_deform_params p;
+    AabbScale sc;
     BwdScratch s;
     float* d_w2[FDGS_NUM_HEADS];
     float* d_b2[FDGS_NUM_HEADS];
@@ -786,7 +796,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);   // at least one head is active (checked on the host)
             L1.preload();
             float q[4], xyz[3];
-            load_query(p, n, q, xyz);
+            load_query(p, d.sc, n, q, xyz);
             f32x16 feat[FT];
 #pragma unroll
             for (int t = 0; t < FT; t++) feat[t] = zero16();
@@ -1266,6 +1276,7 @@ __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
 // ds_add_f32 and is flushed once per workgroup with coalesced global atomics (x w_t0 and x w_t1).
 struct PlaneGradArgs {
     fdgs_deform_params p;
+    AabbScale sc;
     const float* DFEAT;
     float* d_planes[FDGS_MAX_LEVELS][6];
     float* d_xyz;
@@ -1295,24 +1306,30 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
         const bool live = n_raw < n_end;
         const int n = live ? n_raw : n_end - 1;
         float q[4], xyz[3];
-        load_query(p, n, q, xyz);
+        load_query(p, a.sc, n, q, xyz);
         float dq[3] = {0.f, 0.f, 0.f};
         for (int lvl = 0; lvl < p.L; lvl++) {
             const float df = live ? a.DFEAT[(size_t)n * a.F + lvl * C + ch] : 0.f;
             float vk[6], sk[6], tk[6], wA[6], wB[6], wX[6], dsx[6], dsy[6];
-            int oA[6], oB[6], oX[6];
+            uint32_t oA[6], oB[6], oX[6];   // unsigned element offsets: SGPR base + VGPR offset addressing for loads and atomics
+            // one sample per axis (x, y, z, t), shared by the planes that contain the axis
+            AxisSample S[4];
+#pragma unroll
+            for (int ax4 = 0; ax4 < 4; ax4++) S[ax4] = axis_sample(q[ax4], p.res[lvl][ax4]);
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 int ax, bx;
                 plane_axes(k, ax, bx);
-                const int Wd = p.res[lvl][ax], Hd = p.res[lvl][bx];
-                const AxisSample sx = axis_sample(q[ax], Wd), sy = axis_sample(q[bx], Hd);
+                const int Wd = p.res[lvl][ax];
+                const AxisSample sx = S[ax], sy = S[bx];
                 const int xi = xc ? sx.i1 : sx.i0;
                 const float wx = xc ? sx.w1 : sx.w0;
-                oX[k] = xi * C + ch;
-                oA[k] = (sy.i0 * Wd + xi) * C + ch;
-                oB[k] = (sy.i1 * Wd + xi) * C + ch;
-                const float v0 = p.planes[lvl][k][oA[k]], v1 = p.planes[lvl][k][oB[k]];
+                oX[k] = (uint32_t)(xi * C + ch);
+                oA[k] = (uint32_t)((sy.i0 * Wd + xi) * C + ch);
+                oB[k] = (uint32_t)((sy.i1 * Wd + xi) * C + ch);
+                const char* Pb = reinterpret_cast<const char*>(p.planes[lvl][k]);   // SGPR base + 32-bit byte offset
+                const float v0 = *reinterpret_cast<const float*>(Pb + oA[k] * 4u);
+                const float v1 = *reinterpret_cast<const float*>(Pb + oB[k] * 4u);
                 sk[k] = sy.w0 * v0 + sy.w1 * v1;             // d/d(ix) carries sign(xc)
                 tk[k] = wx * (v1 - v0);                      // d/d(iy)
                 float part = wx * sk[k];
@@ -1366,7 +1383,7 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
             }
             if (live && (lane % LPG) == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) a.d_xyz[3 * (size_t)n + i] += dq[i] * (2.0f / (p.aabb[3 + i] - p.aabb[i]));
+                for (int i = 0; i < 3; i++) a.d_xyz[3 * (size_t)n + i] += dq[i] * a.sc.inv2[i];
             }
         }
     }
@@ -1493,7 +1510,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     if (p->N == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeformDev d;
-    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1);
+    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1); d.sc = aabb_scale(p);
     {
         const SavedLayout sl = saved_layout(p);
         float* sv = reinterpret_cast<float*>(out->saved);
@@ -1564,7 +1581,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
     BwdDev bd;
-    bd.p = *p; bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
+    bd.p = *p; bd.sc = aabb_scale(p); bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
     const float* X_rh = s.RH;      // operands of the weight-gradient GEMMs: recomputed into scratch, or saved by the forward
     const float* X_feat = s.FEAT;
     bd.sv_rh = bd.sv_h1 = nullptr;
@@ -1665,7 +1682,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     // plane + coordinate gradients
     bool any_plane = g->d_xyz != nullptr;
     PlaneGradArgs ga{};
-    ga.p = *p; ga.DFEAT = s.DFEAT; ga.d_xyz = g->d_xyz; ga.F = (int)F;
+    ga.p = *p; ga.sc = aabb_scale(p); ga.DFEAT = s.DFEAT; ga.d_xyz = g->d_xyz; ga.F = (int)F;
     for (int l = 0; l < p->L; l++)
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
