@@ -1154,7 +1154,7 @@ constexpr int WG_PD = 6;
 // COLS_IL: X has exactly W columns, column mapping interleaved (vector loads); else tile mapping c = 32*b + j with
 // CT = ceil(ncols/32) dword loads per k-step (the small trunk product, ncols = C*L).
 template <int WT, int CT, bool COLS_IL>
-__device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin, int n_end, float* ldsW, float* ldsB, int g, int h) {
+__device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin, int n_end, float* ldsW, float* ldsB, int g, int h, int wave) {
     constexpr int BV = COLS_IL ? WT : 1, NB = COLS_IL ? 1 : CT;
     f32x16 acc[WT][CT];
 #pragma unroll
@@ -1172,11 +1172,12 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
         col = col < J.ncols ? col : J.ncols - 1;
         bp[b] = J.X + (size_t)(n_begin + h) * J.ldx + col;
     }
-    const int nsteps = (n_end - n_begin) >> 1;   // chunk lengths are even
+    const int nsteps = (n_end - n_begin) >> 1;   // chunk lengths are even; 0 for a wave without work (it still joins the reduction)
     AVec<WT> abuf[WG_PD];
     AVec<BV> bbuf[WG_PD][NB];
 #pragma unroll
     for (int s = 0; s < WG_PD; s++) {
+        if (nsteps == 0) break;
         const int ss = s < nsteps ? s : 0;
         abuf[s] = ldv<WT>(ap + (size_t)ss * 2 * W);
 #pragma unroll
@@ -1205,23 +1206,43 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
             }
         }
     }
-    // workgroup reduction in LDS: ldsW[m * ldl + c], ldl = 32*CT
+    // workgroup reduction in LDS, ldsW[m * ldl + c] with ldl = 32*CT: the four waves take turns (barrier between turns) and
+    // use plain stores / read-add-writes -- ds_add_f32 runs at 0.33 lanes/clk/CU on MI355X (tools/lds_atomic_bench.hip:
+    // 37x slower than ds_add_u32, ~200x slower than plain LDS traffic) and 4 x 16 k float atomics cost ~15 % of this kernel
     constexpr int LDL = 32 * CT;
+    float bsum[WT];
 #pragma unroll
-    for (int a = 0; a < WT; a++)
+    for (int a = 0; a < WT; a++) bsum[a] = asum[a] + __shfl_xor(asum[a], 32, 64);
+    if (wave == 0) {
 #pragma unroll
-        for (int b = 0; b < CT; b++)
+        for (int a = 0; a < WT; a++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = WT * rho(r, h) + a;
-                const int c = COLS_IL ? WT * g + b : 32 * b + g;
-                atomicAdd(&ldsW[m * LDL + c], acc[a][b][r]);
+            for (int b = 0; b < CT; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ldsW[(WT * rho(r, h) + a) * LDL + (COLS_IL ? WT * g + b : 32 * b + g)] = acc[a][b][r];
+        if (h == 0) {
+#pragma unroll
+            for (int a = 0; a < WT; a++) ldsB[WT * g + a] = bsum[a];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int turn = 1; turn < 4; turn++) {
+        if (wave == turn) {
+#pragma unroll
+            for (int a = 0; a < WT; a++)
+#pragma unroll
+                for (int b = 0; b < CT; b++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) ldsW[(WT * rho(r, h) + a) * LDL + (COLS_IL ? WT * g + b : 32 * b + g)] += acc[a][b][r];
+                    __builtin_amdgcn_sched_barrier(0);   // 16 read-add-writes at a time (256 hoisted ds_reads would spill)
+                }
+            if (h == 0) {
+#pragma unroll
+                for (int a = 0; a < WT; a++) ldsB[WT * g + a] += bsum[a];
             }
-#pragma unroll
-    for (int a = 0; a < WT; a++) {
-        float v = asum[a];
-        v += __shfl_xor(v, 32, 64);
-        if (h == 0) atomicAdd(&ldsB[WT * g + a], v);
+        }
+        __syncthreads();
     }
 }
 
@@ -1236,8 +1257,6 @@ __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
         if (q < a.njobs && (int)blockIdx.x >= a.job[q].first_block) j = q;
     const WgradJob J = a.job[j];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
-    for (int i = threadIdx.x; i < W * W + W; i += 256) lds[i] = 0.f;
-    __syncthreads();
     const int blk = (int)blockIdx.x - J.first_block;
     int n_begin = blk * J.chunk, n_end = n_begin + J.chunk;
     if (n_end > a.Npad) n_end = a.Npad;
@@ -1250,14 +1269,12 @@ __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
     float* ldsW = lds;
     float* ldsB = lds + W * W;
     const int CTn = (J.ncols + 31) / 32;
-    if (we > wb) {
-        if (J.ncols == W) wgrad_wave<WT, WT, true>(J, W, wb, we, ldsW, ldsB, g, h);
-        else if (CTn == 1) wgrad_wave<WT, 1, false>(J, W, wb, we, ldsW, ldsB, g, h);
-        else if (CTn == 2) wgrad_wave<WT, 2, false>(J, W, wb, we, ldsW, ldsB, g, h);
-        else if (CTn == 3) wgrad_wave<WT, 3, false>(J, W, wb, we, ldsW, ldsB, g, h);
-        else if constexpr (WT != 4) wgrad_wave<WT, 4, false>(J, W, wb, we, ldsW, ldsB, g, h);   // (W = 128, 128 columns) is the interleaved case
-    }
-    __syncthreads();
+    // (every wave joins, also one whose slice is empty: the reduction inside is a workgroup-wide protocol)
+    if (J.ncols == W) wgrad_wave<WT, WT, true>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 1) wgrad_wave<WT, 1, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 2) wgrad_wave<WT, 2, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 3) wgrad_wave<WT, 3, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if constexpr (WT != 4) wgrad_wave<WT, 4, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);   // (W = 128, 128 columns) is the interleaved case
     const int ldl = J.ncols == W ? W : 32 * CTn;
     for (int i = threadIdx.x; i < W * ldl; i += 256) {
         const int m = i / ldl, c = i - m * ldl;
@@ -1284,7 +1301,6 @@ struct PlaneGradArgs {
     int lds_off[FDGS_MAX_LEVELS][3];  // float offset of the LDS tile of time plane k = 2,4,5 (axis a = 0,1,2); -1: global atomics
     int lds_floats;
     int per_block;                    // Gaussians per workgroup
-    int dev_skip_global_atomics;      // development probe (FDGS_PG_NOATOM): measure the kernel without its global atomics
 };
 constexpr int PG_THREADS = 512;
 __host__ __device__ __forceinline__ int time_plane_slot(int k) { return k == 2 ? 0 : (k == 4 ? 1 : (k == 5 ? 2 : -1)); }
@@ -1301,12 +1317,25 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
     __syncthreads();
     const int n_begin = blockIdx.x * a.per_block;
     const int n_end = n_begin + a.per_block < p.N ? n_begin + a.per_block : p.N;
+    // software pipeline over the workgroup's batches: the coordinates (and frame time) of the NEXT batch are requested
+    // before the current one is processed -- the kernel is latency bound (xyz -> texel addresses -> texels -> atomics)
+    auto fetch_xyz = [&](int nbq, float* x4) {
+        const int nr = nbq + wave * GPW + gsub;
+        const int nn = nr < n_end ? nr : n_end - 1;
+        x4[0] = p.xyz[3 * (size_t)nn]; x4[1] = p.xyz[3 * (size_t)nn + 1]; x4[2] = p.xyz[3 * (size_t)nn + 2];
+        x4[3] = p.time ? p.time[nn] : p.time_scalar;
+    };
+    float xn[4];
+    if (n_begin < n_end) fetch_xyz(n_begin, xn);
     for (int nb = n_begin; nb < n_end; nb += GPB) {
         const int n_raw = nb + wave * GPW + gsub;
         const bool live = n_raw < n_end;
         const int n = live ? n_raw : n_end - 1;
-        float q[4], xyz[3];
-        load_query(p, a.sc, n, q, xyz);
+        float q[4];
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = (xn[i] - p.aabb[i]) * a.sc.inv2[i] - 1.0f;
+        q[3] = xn[3];
+        if (nb + GPB < n_end) fetch_xyz(nb + GPB, xn);
         float dq[3] = {0.f, 0.f, 0.f};
         for (int lvl = 0; lvl < p.L; lvl++) {
             const float df = live ? a.DFEAT[(size_t)n * a.F + lvl * C + ch] : 0.f;
@@ -1361,7 +1390,7 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
                 if (dP && live) {
                     if (loff >= 0) {
                         atomicAdd(&lds[loff + oX[k]], dv * wX[k]);   // ds_add_f32
-                    } else if (!a.dev_skip_global_atomics) {
+                    } else {
                         atomicAdd(&dP[oA[k]], dv * wA[k]);
                         atomicAdd(&dP[oB[k]], dv * wB[k]);
                     }
@@ -1705,7 +1734,6 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             }
         }
         ga.lds_floats = used;
-        ga.dev_skip_global_atomics = tunable("FDGS_PG_NOATOM", 0);
         const int gpb = (PG_THREADS / 64) * (64 / (2 * p->C));       // Gaussians per workgroup iteration
         int nwg = tunable("FDGS_PG_WGS", 512);                        // ~2 workgroups per CU
         int per_block = cdiv(p->N, nwg);

@@ -24,7 +24,6 @@ SWEEPS = [
     ("wg_trunk=4", {"FDGS_WGRAD_TRUNK": "4"}),
     ("wg_trunk=6", {"FDGS_WGRAD_TRUNK": "6"}),
     ("small_heads=0", {"FDGS_SMALL_HEADS": "0"}),
-    ("pg_noatom=1", {"FDGS_PG_NOATOM": "1"}),
     ("pg_lds=0", {"FDGS_PG_LDS": "0"}),
     ("pg_wgs=256", {"FDGS_PG_WGS": "256"}),
     ("pg_wgs=1024", {"FDGS_PG_WGS": "1024"}),
@@ -34,7 +33,7 @@ SWEEPS = [
     ("wgrad_wgs=128", {"FDGS_WGRAD_WGS": "128"}),
     ("wgrad_wgs=512", {"FDGS_WGRAD_WGS": "512"}),
 ]
-KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS", "FDGS_WGRAD_TRUNK", "FDGS_SMALL_HEADS", "FDGS_PG_NOATOM")
+KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS", "FDGS_WGRAD_TRUNK", "FDGS_SMALL_HEADS")
 
 
 def main():
