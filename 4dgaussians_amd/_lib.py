@@ -84,6 +84,8 @@ SYMBOLS = {
     "fdgs_deform_bwd_scratch_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),
     "fdgs_l1_stats": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "fdgs_image_loss_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdgs_image_loss_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "fdgs_plane_regulation": (c_int, [c_void_p, c_int, POINTER(RegPlane), c_float, c_void_p, c_void_p]),
     "fdgs_adam_step": (c_int, [c_void_p, c_int, POINTER(AdamTensor), c_double, c_double, c_double]),
     "fdgs_knn3_mean_dist2": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),

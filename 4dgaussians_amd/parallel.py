@@ -60,3 +60,58 @@ def max_over_ranks(value, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- data-parallel train step: every rank renders its own views, gradients are summed ----
+def allreduce_gradients(params, bucket_bytes=512 << 20, average=False):
+    """Sum (or average) `.grad` of `params` over the ranks, in place.
+
+    The reference sums the losses of the `batch_size` views of one step before one backward (train.py:180-219), so the
+    gradient of a step is the SUM over its views: with the views spread over ranks that is one all-reduce(sum).  Gradients
+    are packed into few large flat buckets first (one for the whole model at 300 k Gaussians: ~71 MB of Gaussian rows +
+    <= 30 MB of planes and MLP weights): xGMI is point-to-point, a ring all-reduce is bound per link, and a handful of
+    100-MB messages use the links far better than hundreds of small tensors would.  Parameters whose grad is None on
+    every rank are skipped; a grad that is None on this rank only is treated as zeros (heads the config switches off get
+    no gradient anywhere, so this cannot deadlock as long as all ranks run the same configuration).
+    Returns the number of collectives issued."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 0
+    world = dist.get_world_size()
+    groups = {}
+    for p in params:
+        if p.grad is None:
+            continue
+        groups.setdefault((p.grad.dtype, p.grad.device), []).append(p.grad)
+    calls = 0
+    for (_, _), grads in sorted(groups.items(), key=lambda kv: str(kv[0])):
+        bucket, size = [], 0
+        for g in grads + [None]:
+            if g is not None and (not bucket or size + g.numel() * g.element_size() <= bucket_bytes):
+                bucket.append(g)
+                size += g.numel() * g.element_size()
+                continue
+            flat = torch.cat([b.reshape(-1) for b in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat.div_(world)
+            off = 0
+            for b in bucket:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            calls += 1
+            bucket, size = ([g], g.numel() * g.element_size()) if g is not None else ([], 0)
+    return calls
+
+
+def allreduce_densification_stats(radii, visibility_filter, viewspace_grad):
+    """Cross-rank form of what train.py:195-196,219-225 does over the views of one step: element-wise MAX of the radii,
+    OR of the visibility masks, SUM of the view-space position gradients.  Returns the three reduced tensors."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return radii, visibility_filter, viewspace_grad
+    r = radii.clone()
+    dist.all_reduce(r, op=dist.ReduceOp.MAX)
+    v = visibility_filter.to(torch.int32)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    g = viewspace_grad.clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    return r, v.bool(), g

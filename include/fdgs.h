@@ -214,6 +214,21 @@ int fdgs_l1_stats(void* stream, size_t n, const float* a, const float* b, float 
                   float* acc);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Image losses of the step right after render() (train.py:201-214): l1_loss (utils/loss_utils.py:20-21), the sum of
+ * squares psnr() needs (utils/image_utils.py:17-38) and ssim() (utils/loss_utils.py:40-66: 11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2), forward value and gradient wrt the rendered image.
+ * img / gt: [items][channels][H][W] contiguous f32 (device).
+ *   fwd: acc[item][4] += { sum|img-gt|, sum (img-gt)^2, channels*H*W, sum of the SSIM map }   (device, caller zero-fills)
+ *        ssim_maps_opt: [3][items*channels][H][W] partial derivatives kept for the backward pass (NULL: value only)
+ *   bwd: dimg = s * ( w_l1 * sign(img-gt) + w_ssim * d(sum SSIM map)/d img ),  s = *grad_scale_dev_opt (device) or 1
+ *        (loss = L1 + lambda (1 - ssim)  ->  w_l1 = 1/n, w_ssim = -lambda/n with n = items*channels*H*W)
+ * ---------------------------------------------------------------------------------------------------------- */
+int fdgs_image_loss_fwd(void* stream, int items, int channels, int H, int W, const float* img, const float* gt,
+                        float* ssim_maps_opt, float* acc);
+int fdgs_image_loss_bwd(void* stream, int items, int channels, int H, int W, const float* img, const float* gt,
+                        const float* ssim_maps, float w_l1, float w_ssim, const float* grad_scale_dev_opt, float* dimg);
+
+/* ------------------------------------------------------------------------------------------------------------
  * HexPlane regulariser: replaces GaussianModel.compute_regulation (scene/gaussian_model.py:538-577 with
  * compute_plane_smoothness of scene/regulation.py:22-28; evaluated at train.py:208-211 every fine iteration).
  *   loss += sum_planes [ w_smooth * mean_{C,H-2,W} (p[h+2] - 2 p[h+1] + p[h])^2 + w_l1 * mean |1 - p| ]

@@ -1,0 +1,124 @@
+"""GPU parity of the image-loss kernels (csrc/loss.hip, fdgs_l1_stats) through fdgs.losses against the CPU oracle and the
+golden vector generated from the reference's utils/loss_utils.py.  Tolerances: values 2e-5 absolute (f32 sums over up to
+4 M pixels, SSIM's sigma = E[x^2] - mu^2 cancellation), gradients 1e-3 relative L2 (the north-star's gradient bound)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as LO
+
+pytestmark = pytest.mark.gpu
+fdgs = importlib.import_module("4dgaussians_amd")
+losses = importlib.import_module("4dgaussians_amd.losses")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_ssim.npz")
+
+
+def _images(shape, seed, noise=0.1):
+    gen = torch.Generator().manual_seed(seed)
+    gt = torch.rand(*shape, generator=gen)
+    if min(shape[-2:]) >= 3:
+        gt = torch.nn.functional.avg_pool2d(gt[None] if gt.dim() == 3 else gt, 3, 1, 1).view(*shape)
+    img = (gt + noise * torch.randn(*shape, generator=gen)).clamp(0, 1)
+    return img, gt
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_golden_vector_from_reference_functions():
+    g = np.load(GOLD)
+    img = torch.from_numpy(g["img"]).cuda().requires_grad_(True)
+    gt = torch.from_numpy(g["gt"]).cuda()
+    lam = float(g["lambda_dssim"])
+    out = losses.image_loss(img, gt, lam)
+    out.loss.backward()
+    assert abs(out.l1.item() - float(g["l1"])) < 1e-6
+    assert abs(out.ssim.item() - float(g["ssim"])) < 2e-5
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-5
+    assert _rel(img.grad.cpu(), torch.from_numpy(g["grad"])) < 1e-3
+    img.grad = None
+    s = losses.ssim(img, gt)
+    s.backward()
+    assert abs(s.item() - float(g["ssim"])) < 2e-5
+    assert _rel(img.grad.cpu(), torch.from_numpy(g["grad_ssim"])) < 1e-3
+    items = losses.ssim(img.detach(), gt, size_average=False)
+    assert np.allclose(items.cpu().numpy(), g["ssim_items"], atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 96), (1, 3, 33, 31), (2, 3, 100, 7), (1, 1, 1, 1), (3, 3, 5, 5), (1, 3, 250, 333)])
+def test_ssim_l1_psnr_against_oracle(shape):
+    img, gt = _images(shape, 11 + sum(shape))
+    a = img.cuda().requires_grad_(True)
+    b = gt.cuda()
+    ao = img.clone().requires_grad_(True)
+    # ssim value + gradient, both reductions
+    s = losses.ssim(a, b)
+    so = LO.ssim(ao, gt)
+    assert abs(s.item() - so.item()) < 2e-5
+    (g,) = torch.autograd.grad(s, a)
+    (go,) = torch.autograd.grad(so, ao)
+    assert g.shape == a.shape and _rel(g.cpu(), go) < 1e-3
+    w = torch.arange(1, (shape[0] if len(shape) == 4 else 1) + 1, dtype=torch.float32)
+    sv = losses.ssim(a, b, size_average=False)
+    svo = LO.ssim(ao, gt, size_average=False)
+    assert torch.allclose(sv.cpu(), svo, atol=2e-5)
+    (g,) = torch.autograd.grad((sv * w.cuda()).sum(), a)
+    (go,) = torch.autograd.grad((svo * w).sum(), ao)
+    assert _rel(g.cpu(), go) < 1e-3
+    # l1 + psnr
+    l = losses.l1_loss(a, b)
+    lo = LO.l1_loss(ao, gt)
+    assert abs(l.item() - lo.item()) < 1e-6
+    (g,) = torch.autograd.grad(l * 3.0, a)
+    (go,) = torch.autograd.grad(lo * 3.0, ao)
+    assert _rel(g.cpu(), go) < 1e-6
+    p = losses.psnr(a, b)
+    po = LO.psnr(img, gt)
+    assert p.shape == po.shape and torch.allclose(p.cpu(), po, atol=1e-3)
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.2])
+def test_fused_image_loss_matches_separate_terms(lam):
+    img, gt = _images((2, 3, 75, 120), 5)
+    a = img.cuda().requires_grad_(True)
+    ao = img.clone().requires_grad_(True)
+    out = losses.image_loss(a, gt.cuda(), lam)
+    ref = LO.l1_loss(ao, gt) + (lam * (1 - LO.ssim(ao, gt)) if lam else 0.0)
+    assert abs(out.loss.item() - ref.item()) < 2e-5
+    (out.loss * 0.5).backward()
+    (ref * 0.5).backward()
+    assert _rel(a.grad.cpu(), ao.grad) < 1e-3
+    assert abs(out.mse.item() - ((img - gt) ** 2).mean().item()) < 1e-6
+    assert torch.isnan(out.ssim).item() == (lam == 0.0)
+
+
+def test_full_size_properties_and_errors():
+    # BASELINE config 4 image size: identical images -> SSIM = 1, zero gradient; linear response of the gradient to the
+    # upstream scalar; error behaviour of the boundary
+    H, W = 1014, 1352
+    img, gt = _images((3, H, W), 3)
+    a = img.cuda().requires_grad_(True)
+    s = losses.ssim(a, a.detach())
+    assert abs(s.item() - 1.0) < 1e-5
+    (g,) = torch.autograd.grad(s, a)
+    assert g.abs().max().item() < 1e-6
+    b = gt.cuda()
+    o1 = losses.image_loss(a, b, 0.2)
+    (g1,) = torch.autograd.grad(o1.loss, a)
+    o2 = losses.image_loss(a, b, 0.2)
+    (g2,) = torch.autograd.grad(o2.loss * 4.0, a)
+    assert torch.equal(o1.loss, o2.loss) or abs(o1.loss.item() - o2.loss.item()) < 1e-6
+    assert _rel(g2, 4.0 * g1) < 1e-6
+    assert 0.0 < o1.ssim.item() < 1.0 and abs(o1.loss.item() - (o1.l1.item() + 0.2 * (1 - o1.ssim.item()))) < 1e-6
+    with pytest.raises(NotImplementedError):
+        losses.ssim(a, b, window_size=7)
+    with pytest.raises(ValueError):
+        losses.ssim(a, b[:, :10])
+    with pytest.raises(fdgs._lib.FdgsError):
+        losses.l1_loss(img, gt)          # CPU tensors: there is no CPU path
+    e = torch.zeros(0, 3, 8, 8, device="cuda")
+    assert losses.mse(e, e).shape == (0, 1)

@@ -64,8 +64,58 @@ def test_two_rank_frame_parallel_loss_allreduce():
         assert r[4] == 1.5                                          # max over ranks
 
 
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    par.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(7)
+    shapes = [(50, 3), (50, 16, 3), (7,), (4, 4), (1,)]
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    views = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(world)]     # same on every rank
+    for p, gr in zip(params, views[rank]):
+        p.grad = gr.clone()
+    params.append(torch.nn.Parameter(torch.zeros(3)))                                  # no grad anywhere: skipped
+    calls_small = par.allreduce_gradients(params, bucket_bytes=1024)                  # forces several buckets
+    small = [p.grad.clone() for p in params[:-1]]
+    for p, gr in zip(params, views[rank]):
+        p.grad = gr.clone()
+    calls_big = par.allreduce_gradients(params, average=True)
+    radii = torch.tensor([1, 5, 0, 2]) if rank == 0 else torch.tensor([3, 0, 0, 9])
+    vis = radii > 0
+    r, v, vg = par.allreduce_densification_stats(radii, vis, torch.full((4, 3), float(rank + 1)))
+    q.put((rank, calls_small, calls_big, [t.tolist() for t in small], [p.grad.tolist() for p in params[:-1]], r.tolist(), v.tolist(), vg.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_and_densification_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    shapes = [(50, 3), (50, 16, 3), (7,), (4, 4), (1,)]
+    views = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(world)]
+    want = [views[0][i] + views[1][i] for i in range(len(shapes))]
+    for r in res:
+        assert r[1] > 1 and r[2] == 1                                # bucketing: several small buckets vs one large
+        for got, w in zip(r[3], want):
+            assert torch.allclose(torch.tensor(got), w, atol=1e-6)
+        for got, w in zip(r[4], want):
+            assert torch.allclose(torch.tensor(got), w / 2, atol=1e-6)
+        assert r[5] == [3, 5, 0, 9] and r[6] == [True, True, False, True]
+        assert torch.allclose(torch.tensor(r[7]), torch.full((4, 3), 3.0))
+
+
 def test_single_process_is_a_noop():
     par = importlib.import_module("4dgaussians_amd.parallel")
     acc = torch.tensor([1.0, 2.0, 3.0])
     assert torch.equal(par.allreduce_loss_stats(acc.clone()), acc)
     assert par.frames_for_rank(160, 5, 0, 1) == 5
+    p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.ones(3)
+    assert par.allreduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))
