@@ -60,6 +60,21 @@ class AdamTensor(Structure):
                 ("lr", c_float), ("step", c_int)]
 
 
+NGROUPS = 6
+
+
+class GaussiansIn(Structure):
+    _fields_ = [("N", c_int), ("width", c_int * NGROUPS), ("param", c_void_p * NGROUPS), ("exp_avg", c_void_p * NGROUPS),
+                ("exp_avg_sq", c_void_p * NGROUPS), ("deformation_table", c_void_p), ("xyz_gradient_accum", c_void_p),
+                ("denom", c_void_p), ("max_radii2D", c_void_p), ("deformation_accum", c_void_p)]
+
+
+class GaussiansOut(Structure):
+    _fields_ = [("param", c_void_p * NGROUPS), ("exp_avg", c_void_p * NGROUPS), ("exp_avg_sq", c_void_p * NGROUPS),
+                ("deformation_table", c_void_p), ("xyz_gradient_accum", c_void_p), ("denom", c_void_p),
+                ("max_radii2D", c_void_p), ("deformation_accum", c_void_p)]
+
+
 # every symbol include/fdgs.h declares: (restype, argtypes)
 SYMBOLS = {
     "fdgs_last_error": (c_char_p, []),
@@ -89,6 +104,11 @@ SYMBOLS = {
     "fdgs_plane_regulation": (c_int, [c_void_p, c_int, POINTER(RegPlane), c_float, c_void_p, c_void_p]),
     "fdgs_adam_step": (c_int, [c_void_p, c_int, POINTER(AdamTensor), c_double, c_double, c_double]),
     "fdgs_knn3_mean_dist2": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "fdgs_densification_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "fdgs_densify_scratch_bytes": (c_int, [c_int, POINTER(c_size_t)]),
+    "fdgs_densify_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_float, c_float, c_float, c_float, c_float, c_void_p, POINTER(c_uint32)]),
+    "fdgs_densify_apply": (c_int, [c_void_p, POINTER(GaussiansIn), POINTER(GaussiansOut), c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfdgs.so")
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "deform.hip", "regulation.hip", "adam.hip", "knn.hip", "loss.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "deform.hip", "regulation.hip", "adam.hip", "knn.hip", "loss.hip", "densify.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 

@@ -57,6 +57,24 @@ inline int tunable(const char* name, int dflt) {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// block-wide exclusive prefix of one value per thread (256 threads); *total = sum over the block
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wtmp /*[4] LDS*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o, 64);
+        if (lane >= (uint32_t)o) inc += u;
+    }
+    if (lane == 63) wtmp[w] = inc;
+    __syncthreads();
+    const uint32_t s0 = wtmp[0], s1 = wtmp[1], s2 = wtmp[2], s3 = wtmp[3];
+    const uint32_t wp = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+    *total = s0 + s1 + s2 + s3;
+    __syncthreads();  // wtmp may be reused by the caller's next round
+    return wp + inc - v;
+}
+
 // ---- radix sort geometry (binning.hip) ----
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;                       // keys per thread

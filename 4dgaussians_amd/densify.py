@@ -1,0 +1,194 @@
+"""Densification bookkeeping of the Gaussian set: drop-ins for the GaussianModel methods the train loop calls on the
+consumer side of render()'s `radii` / `viewspace_points.grad` (train.py:259-285):
+
+    gaussians.add_densification_stats(grad, visibility_filter)   ->  fdgs.densify.add_densification_stats(gaussians, grad, visibility_filter, radii)
+                                                                     (also does train.py:261's max_radii2D update; one launch, no host sync)
+    gaussians.densify(max_grad, min_opacity, extent, size, ...)  ->  fdgs.densify.densify(gaussians, max_grad, min_opacity, extent, size, ...)
+    gaussians.prune(max_grad, min_opacity, extent, size)         ->  fdgs.densify.prune(gaussians, ...)
+    gaussians.prune_points(mask)                                 ->  fdgs.densify.prune_points(gaussians, mask)
+    gaussians.reset_opacity()                                    ->  fdgs.densify.reset_opacity(gaussians)
+
+(scene/gaussian_model.py:269-272, 316-456, 481-500, 516-518).  `gaussians` is the reference's GaussianModel (or anything
+with the same attributes: _xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation, optimizer with the named
+param groups, xyz_gradient_accum, denom, max_radii2D, _deformation_accum, _deformation_table, percent_dense).  Clone,
+split and prune run as a plan (classify + scan, ONE readback of three counts) and one apply launch that writes all six
+Parameters, both Adam moments and the side arrays (csrc/densify.hip); the optimizer-state surgery keeps the reference's
+contract: new nn.Parameter objects in the same param_groups, `exp_avg` / `exp_avg_sq` rows of kept Gaussians preserved,
+zeros for new rows, `step` untouched.  No CPU fallback.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import GaussiansIn, GaussiansOut, check, ptr, stream_ptr
+
+GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+        "rotation": "_rotation"}
+PLAN_DENSIFY, PLAN_PRUNE, PLAN_MASK = 0, 1, 2
+
+
+def _rows(n, tail, dev, dtype=torch.float32):
+    """([n, *tail] uninitialised, its device address); backed by at least one row because torch reports a NULL data_ptr for
+    empty tensors and the C-ABI treats NULL outputs as errors / "skip"."""
+    base = torch.empty((max(n, 1),) + tuple(tail), device=dev, dtype=dtype)
+    return base[:n], base.data_ptr()
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous()
+
+
+def add_densification_stats(pc, viewspace_point_tensor_grad, update_filter, radii=None):
+    """xyz_gradient_accum[f] += |grad[f, :2]|, denom[f] += 1 (scene/gaussian_model.py:516-518) and, when `radii` is given,
+    max_radii2D[f] = max(max_radii2D[f], radii[f]) (train.py:261), in place, without the host syncs of boolean indexing."""
+    g = viewspace_point_tensor_grad
+    if g.device.type != "cuda":
+        raise _lib.FdgsError("the densification kernels run on the GPU only")
+    g = _f32(g.detach())
+    n = g.shape[0]
+    vis = update_filter.contiguous().view(torch.uint8) if update_filter.dtype == torch.bool else (update_filter != 0).view(torch.uint8)
+    r = None
+    if radii is not None:
+        r = radii if radii.dtype == torch.int32 and radii.is_contiguous() else radii.to(torch.int32).contiguous()
+    for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        t = getattr(pc, name)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous float32 tensor")
+    check(_lib.lib().fdgs_densification_stats(stream_ptr(), n, ptr(r), ptr(vis), ptr(g), g.shape[1], ptr(pc.max_radii2D) if r is not None else None,
+                                              ptr(pc.xyz_gradient_accum), ptr(pc.denom)))
+
+
+def _groups(pc):
+    by_name = {}
+    for group in pc.optimizer.param_groups:
+        if len(group["params"]) == 1 and group.get("name") in GROUPS:
+            by_name[group["name"]] = group
+    missing = [n for n in GROUPS if n not in by_name]
+    if missing:
+        raise ValueError(f"optimizer has no single-tensor param group named {missing}")
+    return by_name
+
+
+def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.0, max_screen_size=0.0, max_world_size=0.0,
+                 drop_mask=None, normals=None, carry_stats=True):
+    L = _lib.lib()
+    groups = _groups(pc)
+    params = {n: groups[n]["params"][0] for n in GROUPS}
+    dev = params["xyz"].device
+    if dev.type != "cuda":
+        raise _lib.FdgsError("the densification kernels run on the GPU only")
+    N = params["xyz"].shape[0]
+    src = {n: _f32(params[n].detach()) for n in GROUPS}
+    nbytes = ctypes.c_size_t()
+    check(L.fdgs_densify_scratch_bytes(N, ctypes.byref(nbytes)))
+    scratch = torch.empty(max(nbytes.value, 16), dtype=torch.uint8, device=dev)
+    counts = (ctypes.c_uint32 * 3)()
+    accum, denom = _f32(pc.xyz_gradient_accum), _f32(pc.denom)
+    radii2d = _f32(pc.max_radii2D)
+    mask8 = None
+    if drop_mask is not None:
+        mask8 = (drop_mask if drop_mask.dtype == torch.bool else drop_mask != 0).contiguous().view(torch.uint8)
+    check(L.fdgs_densify_plan(stream_ptr(), mode, N, ptr(accum), ptr(denom), ptr(src["scaling"]), ptr(src["opacity"]), ptr(radii2d),
+                              ptr(mask8), grad_threshold, dense_size, min_opacity, max_screen_size, max_world_size, ptr(scratch), counts))
+    kept, clones, splits = int(counts[0]), int(counts[1]), int(counts[2])
+    n_out = kept + clones + 2 * splits
+    if splits and normals is None:
+        normals = torch.randn(2 * splits, 3, device=dev)
+    if normals is not None:
+        normals = _f32(normals)
+        if normals.shape[0] < 2 * splits:
+            raise ValueError("need 2 * splits rows of standard-normal samples")
+        normals = normals[:2 * splits].contiguous()
+
+    gin, gout = GaussiansIn(), GaussiansOut()
+    gin.N = N
+    new_param, new_m, new_v, states = {}, {}, {}, {}
+    for i, n in enumerate(GROUPS):
+        p = src[n]
+        w = 1
+        for d in p.shape[1:]:
+            w *= int(d)
+        gin.width[i] = w
+        gin.param[i] = p.data_ptr()
+        st = pc.optimizer.state.get(params[n], None)
+        states[n] = st
+        has = st is not None and "exp_avg" in st
+        m = _f32(st["exp_avg"]) if has else None
+        v = _f32(st["exp_avg_sq"]) if has else None
+        gin.exp_avg[i] = m.data_ptr() if has else None
+        gin.exp_avg_sq[i] = v.data_ptr() if has else None
+        new_param[n], gout.param[i] = _rows(n_out, p.shape[1:], dev)
+        if has:
+            new_m[n], gout.exp_avg[i] = _rows(n_out, p.shape[1:], dev)
+            new_v[n], gout.exp_avg_sq[i] = _rows(n_out, p.shape[1:], dev)
+        states[n] = (st, m, v)                                  # keeps m / v alive until the launch is queued
+    table = pc._deformation_table
+    table8 = table.contiguous().view(torch.uint8) if table.dtype == torch.bool else (table != 0).view(torch.uint8)
+    new_table, gout.deformation_table = _rows(n_out, (), dev, torch.uint8)
+    gin.deformation_table = table8.data_ptr()
+    dacc = _f32(pc._deformation_accum)
+    if carry_stats:
+        new_stats = {}
+        new_stats["xyz_gradient_accum"], gout.xyz_gradient_accum = _rows(n_out, (1,), dev)
+        new_stats["denom"], gout.denom = _rows(n_out, (1,), dev)
+        new_stats["max_radii2D"], gout.max_radii2D = _rows(n_out, (), dev)
+        new_stats["_deformation_accum"], gout.deformation_accum = _rows(n_out, (3,), dev)
+        gin.xyz_gradient_accum, gin.denom, gin.max_radii2D, gin.deformation_accum = accum.data_ptr(), denom.data_ptr(), radii2d.data_ptr(), dacc.data_ptr()
+    else:   # densification_postfix re-creates the four statistics as zeros of the new size
+        new_stats = {"xyz_gradient_accum": torch.zeros(n_out, 1, device=dev), "denom": torch.zeros(n_out, 1, device=dev),
+                     "max_radii2D": torch.zeros(n_out, device=dev), "_deformation_accum": torch.zeros(n_out, 3, device=dev)}
+    check(L.fdgs_densify_apply(stream_ptr(), ctypes.byref(gin), ctypes.byref(gout), ptr(scratch), ptr(normals)))
+
+    for n in GROUPS:
+        st = states[n][0]
+        new = nn.Parameter(new_param[n].requires_grad_(True))
+        if st is not None:
+            if n in new_m:
+                st["exp_avg"], st["exp_avg_sq"] = new_m[n], new_v[n]
+            del pc.optimizer.state[params[n]]
+            pc.optimizer.state[new] = st
+        groups[n]["params"][0] = new
+        setattr(pc, ATTR[n], new)
+    pc._deformation_table = new_table.view(torch.bool)
+    for k, v in new_stats.items():
+        setattr(pc, k, v)
+    return kept, clones, splits
+
+
+def densify(pc, max_grad, min_opacity, extent, max_screen_size, density_threshold=None, displacement_scale=None, model_path=None,
+            iteration=None, stage=None, normals=None):
+    """GaussianModel.densify (scene/gaussian_model.py:495-500): clone the small high-gradient Gaussians, split the large
+    ones into two.  `normals` ([2*splits, 3] standard-normal samples) may be supplied for reproducibility; by default they
+    come from torch.randn on the device.  Returns (kept, clones, splits)."""
+    return _restructure(pc, PLAN_DENSIFY, grad_threshold=float(max_grad), dense_size=float(pc.percent_dense) * float(extent),
+                        normals=normals, carry_stats=False)
+
+
+def prune(pc, max_grad, min_opacity, extent, max_screen_size):
+    """GaussianModel.prune (scene/gaussian_model.py:481-494): drop transparent, screen-filling or oversized Gaussians."""
+    return _restructure(pc, PLAN_PRUNE, min_opacity=float(min_opacity), max_screen_size=float(max_screen_size or 0.0),
+                        max_world_size=0.1 * float(extent))
+
+
+def prune_points(pc, mask):
+    """GaussianModel.prune_points (scene/gaussian_model.py:350-365): drop the Gaussians where `mask` is True."""
+    return _restructure(pc, PLAN_MASK, drop_mask=mask)
+
+
+def reset_opacity(pc):
+    """GaussianModel.reset_opacity (scene/gaussian_model.py:269-272): opacity <- inverse_sigmoid(min(sigmoid(o), 0.01)), Adam
+    moments of the opacity group zeroed.  Two elementwise device ops; no kernel of its own."""
+    group = _groups(pc)["opacity"]
+    old = group["params"][0]
+    x = torch.clamp_max(torch.sigmoid(old.detach()), 0.01)
+    new = nn.Parameter(torch.log(x / (1 - x)).requires_grad_(True))
+    st = pc.optimizer.state.get(old, None)
+    if st is not None:
+        st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(new), torch.zeros_like(new)
+        del pc.optimizer.state[old]
+        pc.optimizer.state[new] = st
+    group["params"][0] = new
+    pc._opacity = new

@@ -17,6 +17,7 @@ import math
 import os
 import sys
 import time
+import types
 
 import torch
 
@@ -92,7 +93,7 @@ def main():
         fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc)))
         img.backward(dimg)
         par.allreduce_loss_stats(acc)   # the only cross-GPU exchange of the path
-        info["radii"] = res["radii"]
+        info["radii"], info["vsp"], info["vis"] = res["radii"], res["viewspace_points"], res["visibility_filter"]
         return acc
 
     for i in range(args.warmup):
@@ -174,9 +175,12 @@ def main():
     train = None
     if not args.no_train_step:
         opt = fdgs.FusedAdam(pc.optimizer_groups(lr=0.0), lr=0.0, eps=1e-15)
+        dstat = types.SimpleNamespace(xyz_gradient_accum=torch.zeros(N, 1, device=dev), denom=torch.zeros(N, 1, device=dev),
+                                      max_radii2D=torch.zeros(N, device=dev))
 
         def train_iter(i):
             step(i)
+            fdgs.densify.add_densification_stats(dstat, info["vsp"].grad, info["vis"], info["radii"])   # train.py:259-262
             reg = fdgs.compute_regulation(pc, 0.01, 0.0001, 0.0001)     # arguments/__init__.py:85-87 defaults
             reg.backward()
             opt.step()
@@ -199,10 +203,10 @@ def main():
         extra = {}
         for line in buf2.value.decode().strip().splitlines():
             name, cnt, tot = line.split()
-            if name in ("plane_regulation", "adam_step"):
+            if name in ("plane_regulation", "adam_step", "densification_stats"):
                 extra[name] = round(float(tot) / 4, 4)
         train = {"iterations_per_s": world * args.steps / dt_tr, "ms_per_iteration": dt_tr / args.steps * 1e3,
-                 "includes": "render fwd+bwd, L1 stats, HexPlane regulariser fwd+bwd, FusedAdam step over all 8 parameter groups (lr = 0)",
+                 "includes": "render fwd+bwd, L1 stats, densification statistics, HexPlane regulariser fwd+bwd, FusedAdam step over all 8 parameter groups (lr = 0)",
                  "extra_kernels_ms_per_iteration": extra}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -270,6 +270,69 @@ int fdgs_adam_step(void* stream, int ntensors, const fdgs_adam_tensor* tensors /
  * ---------------------------------------------------------------------------------------------------------- */
 int fdgs_knn3_mean_dist2(void* stream, int N, const float* points, float* mean_dist2);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Densification bookkeeping (the consumer of render()'s radii / viewspace_points.grad).
+ *
+ * fdgs_densification_stats: train.py:259-262 + GaussianModel.add_densification_stats (scene/gaussian_model.py:516-518),
+ *   for every visible Gaussian (visibility_opt != 0, or radii > 0 when it is NULL):
+ *     max_radii2D = max(max_radii2D, radii)   (skipped when max_radii2D_opt is NULL)
+ *     xyz_gradient_accum += |viewspace_grad[:, :2]|,  denom += 1            (viewspace_grad rows of grad_stride floats)
+ *
+ * fdgs_densify_plan / fdgs_densify_apply: GaussianModel.densify (densify_and_clone + densify_and_split,
+ *   scene/gaussian_model.py:409-456, 495-500), GaussianModel.prune / prune_points (:350-365, 481-494) with the
+ *   optimizer-state surgery of cat_tensors_to_optimizer / _prune_optimizer (:331-348, 367-389).
+ *   plan  FDGS_PLAN_DENSIFY: g = accum/denom (NaN -> 0), big = max(exp(scaling)) > dense_size (= percent_dense * extent):
+ *                            clone when |g| >= grad_threshold and not big; split (N = 2) when g >= grad_threshold and big
+ *         FDGS_PLAN_PRUNE  : drop when sigmoid(opacity) < min_opacity, or (max_screen_size > 0 and (max_radii2D >
+ *                            max_screen_size or max(exp(scaling)) > max_world_size (= 0.1 * extent)))
+ *         FDGS_PLAN_MASK   : drop where drop_mask != 0 (prune_points(mask))
+ *         counts_host[3] = { rows kept, clones, split Gaussians }: the ONE blocking readback (the reference syncs on
+ *         .any() / .sum() / boolean indexing many times); N_out = kept + clones + 2 * splits.
+ *   apply writes every output row exactly once, order [kept originals | clones | first children | second children];
+ *         exp_avg / exp_avg_sq of new rows are 0 (NULL inputs = no optimizer state yet = zeros; NULL outputs = skipped);
+ *         side arrays: deformation_table follows its Gaussian, the four statistics survive on kept rows and are 0 on
+ *         new rows (any of them may be NULL in `out`).  split_samples: [2*splits][3] standard normals, row
+ *         k*splits + r belongs to child k of the r-th split Gaussian (torch.normal over stds.repeat(2,1)); NULL puts
+ *         the children on their parent.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define FDGS_NGROUPS 6          /* xyz, f_dc, f_rest, opacity, scaling, rotation (scene/gaussian_model.py:176-185) */
+#define FDGS_PLAN_DENSIFY 0
+#define FDGS_PLAN_PRUNE 1
+#define FDGS_PLAN_MASK 2
+typedef struct {
+    int N;                                  /* Gaussians before */
+    int width[FDGS_NGROUPS];                /* floats per row: 3, 3, 3*((deg+1)^2-1), 1, 3, 4 (0 = group absent) */
+    const float* param[FDGS_NGROUPS];
+    const float* exp_avg[FDGS_NGROUPS];
+    const float* exp_avg_sq[FDGS_NGROUPS];
+    const uint8_t* deformation_table;       /* opt [N] */
+    const float* xyz_gradient_accum;        /* opt [N] */
+    const float* denom;                     /* opt [N] */
+    const float* max_radii2D;               /* opt [N] */
+    const float* deformation_accum;         /* opt [N,3] */
+} fdgs_gaussians_in;
+typedef struct {
+    float* param[FDGS_NGROUPS];             /* [N_out][width] */
+    float* exp_avg[FDGS_NGROUPS];
+    float* exp_avg_sq[FDGS_NGROUPS];
+    uint8_t* deformation_table;
+    float* xyz_gradient_accum;
+    float* denom;
+    float* max_radii2D;
+    float* deformation_accum;
+} fdgs_gaussians_out;
+
+int fdgs_densification_stats(void* stream, int N, const int32_t* radii, const uint8_t* visibility_opt,
+                             const float* viewspace_grad, int grad_stride, float* max_radii2D_opt,
+                             float* xyz_gradient_accum, float* denom);
+int fdgs_densify_scratch_bytes(int N, size_t* bytes);
+int fdgs_densify_plan(void* stream, int mode, int N, const float* xyz_gradient_accum, const float* denom,
+                      const float* scaling, const float* opacity, const float* max_radii2D, const uint8_t* drop_mask,
+                      float grad_threshold, float dense_size, float min_opacity, float max_screen_size,
+                      float max_world_size, void* scratch, uint32_t* counts_host);
+int fdgs_densify_apply(void* stream, const fdgs_gaussians_in* in, const fdgs_gaussians_out* out, const void* scratch,
+                       const float* split_samples_opt);
+
 #ifdef __cplusplus
 }
 #endif

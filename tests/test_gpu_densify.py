@@ -1,0 +1,149 @@
+"""GPU parity of the densification kernels (csrc/densify.hip) through fdgs.densify against the CPU oracle and the golden
+vector produced by the reference's own GaussianModel methods.  Row order, counts, the deformation table and every copied
+value must be bit-exact; the two computed quantities (children positions and scales: exp / log / sqrt in f32) are held to
+1e-5 absolute."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import densify_oracle as DO
+from test_oracle_densify import GOLD, assert_states_equal, load_state
+
+pytestmark = pytest.mark.gpu
+fdgs = importlib.import_module("4dgaussians_amd")
+dn = importlib.import_module("4dgaussians_amd.densify")
+ATTR = dn.ATTR
+
+
+class Model:
+    """The attributes of the reference's GaussianModel that the densification methods touch."""
+
+
+def model_from_state(st, percent_dense=0.01, fused=True, with_state=True):
+    m = Model()
+    m.percent_dense = percent_dense
+    groups = []
+    for n in DO.GROUPS:
+        p = torch.nn.Parameter(st["param"][n].cuda().requires_grad_(True))
+        setattr(m, ATTR[n], p)
+        groups.append({"params": [p], "lr": 0.0, "name": n})
+    extra = torch.nn.Parameter(torch.zeros(5, device="cuda"))
+    groups.insert(1, {"params": [extra, torch.nn.Parameter(torch.zeros(2, device="cuda"))], "lr": 0.0, "name": "deformation"})
+    m.optimizer = (fdgs.FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    if with_state:
+        for gr in m.optimizer.param_groups:
+            if gr["name"] in DO.GROUPS:
+                m.optimizer.state[gr["params"][0]] = {"step": torch.tensor(7.0), "exp_avg": st["exp_avg"][gr["name"]].cuda(),
+                                                     "exp_avg_sq": st["exp_avg_sq"][gr["name"]].cuda()}
+    m.xyz_gradient_accum = st["xyz_gradient_accum"].cuda()
+    m.denom = st["denom"].cuda()
+    m.max_radii2D = st["max_radii2D"].cuda()
+    m._deformation_accum = st["deformation_accum"].cuda()
+    m._deformation_table = st["deformation_table"].cuda()
+    return m
+
+
+def state_from_model(m, like=None):
+    st = {"param": {}, "exp_avg": {}, "exp_avg_sq": {}}
+    for gr in m.optimizer.param_groups:
+        if gr["name"] not in DO.GROUPS:
+            continue
+        p = gr["params"][0]
+        assert p is getattr(m, ATTR[gr["name"]]) and p.requires_grad and p.is_leaf
+        st["param"][gr["name"]] = p.detach().cpu()
+        s = m.optimizer.state.get(p)
+        if s is not None:
+            assert float(s["step"]) == 7.0
+            st["exp_avg"][gr["name"]] = s["exp_avg"].cpu()
+            st["exp_avg_sq"][gr["name"]] = s["exp_avg_sq"].cpu()
+        else:
+            st["exp_avg"][gr["name"]] = like["exp_avg"][gr["name"]]
+            st["exp_avg_sq"][gr["name"]] = like["exp_avg_sq"][gr["name"]]
+    st["xyz_gradient_accum"], st["denom"] = m.xyz_gradient_accum.cpu(), m.denom.cpu()
+    st["max_radii2D"], st["deformation_accum"] = m.max_radii2D.cpu(), m._deformation_accum.cpu()
+    st["deformation_table"] = m._deformation_table.cpu()
+    return st
+
+
+def test_golden_sequence_from_reference_methods():
+    g = np.load(GOLD)
+    _, _, pd, extent, max_grad = [float(v) for v in g["meta"]]
+    m = model_from_state(load_state(g, "in"), pd)
+    dn.add_densification_stats(m, torch.from_numpy(g["vgrad"]).cuda(), torch.from_numpy(g["vis"]).cuda(), torch.from_numpy(g["radii"]).cuda())
+    assert_states_equal(state_from_model(m), load_state(g, "stats"), tol=1e-7)
+    kept, clones, splits = dn.densify(m, max_grad, 0.005, extent, 20, 5, 5, normals=torch.from_numpy(g["normals"]).cuda())
+    want = load_state(g, "densified")
+    assert kept + clones + 2 * splits == want["param"]["xyz"].shape[0] and clones > 20 and splits > 20
+    assert_states_equal(state_from_model(m), want, tol=1e-5)
+    m.max_radii2D = torch.from_numpy(g["radii_after"]).cuda()
+    dn.prune(m, max_grad, 0.05, extent, 20)
+    assert_states_equal(state_from_model(m), load_state(g, "pruned"), tol=1e-5)
+    dn.reset_opacity(m)
+    assert_states_equal(state_from_model(m), load_state(g, "reset"), tol=1e-5)
+    # the optimizer still steps on the new Parameters
+    for n in DO.GROUPS:
+        p = getattr(m, ATTR[n])
+        p.grad = torch.ones_like(p)
+    m.optimizer.step()
+
+
+@pytest.mark.parametrize("n,seed,sh_rest,size,fused", [(5000, 1, 15, 20, True), (1025, 2, 0, None, False), (1, 3, 15, 20, True),
+                                                        (2048, 4, 8, 20, True), (300000, 5, 15, 20, True)])
+def test_densify_prune_against_oracle(n, seed, sh_rest, size, fused):
+    st = DO.random_state(n, seed, sh_rest=sh_rest)
+    normals = torch.randn(2 * n, 3, generator=torch.Generator().manual_seed(seed))
+    m = model_from_state(st, fused=fused)
+    o = DO.clone_state(st)
+    kept, clones, splits = dn.densify(m, 0.0002, 0.005, 3.0, size, normals=normals.cuda())
+    nc, ns = DO.densify(o, 0.0002, 3.0, 0.01, normals)
+    assert (clones, splits, kept) == (nc, ns, n - ns)
+    assert_states_equal(state_from_model(m), o, tol=1e-5)
+    copied = ("f_dc", "f_rest", "opacity", "rotation")                      # pure copies: bit-exact
+    got = state_from_model(m)
+    for k in copied:
+        assert torch.equal(got["param"][k], o["param"][k])
+    r = torch.rand(o["param"]["xyz"].shape[0], generator=torch.Generator().manual_seed(seed + 1)) * 40
+    m.max_radii2D, o["max_radii2D"] = r.cuda(), r.clone()
+    m.xyz_gradient_accum += 1.5                                              # prune carries the statistics of kept rows
+    o["xyz_gradient_accum"] += 1.5
+    dn.prune(m, 0.0002, 0.05, 3.0, size)
+    DO.prune(o, 0.05, 3.0, size)
+    assert_states_equal(state_from_model(m), o, tol=1e-5)
+    mask = torch.rand(o["param"]["xyz"].shape[0], generator=torch.Generator().manual_seed(seed + 2)) < 0.5
+    dn.prune_points(m, mask.cuda())
+    DO.prune_points(o, mask)
+    assert_states_equal(state_from_model(m), o, tol=1e-5)
+
+
+def test_edge_cases_nothing_selected_all_pruned_no_optimizer_state():
+    st = DO.random_state(700, 9, sh_rest=3)
+    st["xyz_gradient_accum"].zero_()                                         # nothing clones or splits
+    m = model_from_state(st, with_state=False)                               # optimizer has not stepped yet
+    o = DO.clone_state(st)
+    assert dn.densify(m, 0.0002, 0.005, 3.0, 20) == (700, 0, 0)
+    DO.densify(o, 0.0002, 3.0, 0.01, torch.zeros(0, 3))
+    assert_states_equal(state_from_model(m, like=o), o)
+    assert m.xyz_gradient_accum.abs().sum().item() == 0 and m.max_radii2D.abs().sum().item() == 0   # postfix resets them
+    dn.prune_points(m, torch.ones(700, dtype=torch.bool, device="cuda"))     # everything goes
+    assert m._xyz.shape == (0, 3) and m._features_rest.shape == (0, 3, 3) and m._deformation_table.shape == (0,)
+    assert dn.prune_points(m, torch.zeros(0, dtype=torch.bool, device="cuda")) == (0, 0, 0)
+    with pytest.raises(fdgs._lib.FdgsError):
+        dn.add_densification_stats(m, torch.zeros(4, 3), torch.zeros(4, dtype=torch.bool))          # CPU tensors: no CPU path
+
+
+def test_stats_kernel_against_boolean_indexing():
+    n = 100003
+    g = torch.Generator().manual_seed(1)
+    st = DO.random_state(n, 7, sh_rest=0)
+    m = model_from_state(st)
+    for it in range(3):
+        vg = torch.randn(n, 3, generator=g) * 1e-3
+        radii = torch.randint(0, 80, (n,), generator=g, dtype=torch.int32)
+        vis = radii > 5
+        dn.add_densification_stats(m, vg.cuda(), vis.cuda(), radii.cuda())
+        DO.add_densification_stats(st, vg, vis, radii)
+    assert torch.equal(m.denom.cpu(), st["denom"]) and torch.equal(m.max_radii2D.cpu(), st["max_radii2D"])
+    assert (m.xyz_gradient_accum.cpu() - st["xyz_gradient_accum"]).abs().max().item() < 1e-8
