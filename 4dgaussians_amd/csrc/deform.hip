@@ -103,6 +103,7 @@ struct DeformDev {
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
     // optional saved activations for the backward (rows < Npad): features [Np][F], relu(hidden) [Np][W], relu(h1) [slot][Np][W]
     float *sv_feat, *sv_rh, *sv_h1;
+    uint32_t* sv_hmask;             // [Npad/32][64 lanes][4]: bit r of word t = relu(hidden) tile t register r > 0 (what D2's lane needs)
     int Npad;
     int head_slot[FDGS_NUM_HEADS];
 };
@@ -481,6 +482,14 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         }
     };
     if (d.sv_rh) park(hid, d.sv_rh + tile_n0 * W);
+    if (d.sv_hmask) {   // the backward's ReLU mask of the trunk output, in its own lane layout: one 16-byte load there
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < WT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) m[t] |= (hid[t][r] > 0.f ? 1u : 0u) << r;
+        reinterpret_cast<uint4*>(d.sv_hmask)[(size_t)(tile_n0 / 32) * 64 + lane] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
 
     const bool writer = live && h == 0;
     // epilogue of head hd applied to the head's output delta (zero for a switched-off head: it returns its input
@@ -702,6 +711,7 @@ struct BwdDev {
     int F;
     int head_slot[FDGS_NUM_HEADS];  // index of the head's dH1 slab
     int ntiles;                     // 32-Gaussian tiles (Npad / 32)
+    const uint32_t* sv_hmask;       // SAVED kernels: the forward's per-lane ReLU bits of the trunk output
     const float *sv_rh, *sv_h1;     // SAVED kernels: relu(hidden) [Np][W], relu(h1) [slot][Np][W] written by the forward
     int small_heads;                // 1: dW2 of the k<=4 heads on the 4x4x1 MFMA with register-resident sums (FDGS_SMALL_HEADS)
     unsigned long long* prof;       // development builds (-DFDGS_PROFILE_D2): per-wave cycle sums per phase
@@ -777,6 +787,10 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
     const unsigned long long prof_t0 = prof_t;
 #endif
+#define FDGS_TV_LIST(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
+#define FDGS_TV_DECL(j) float4 tv##j = make_float4(0.f, 0.f, 0.f, 0.f);
+    FDGS_TV_LIST(FDGS_TV_DECL)
+    bool tv_loaded = false;   // SAVED: the first head's relu(h1) tile of this tile was requested during the previous tile
     for (int tile = blockIdx.x * 4 + wave; tile < d.ntiles; tile += gridDim.x * 4) {
         // opaque per-iteration copies of the lane coordinates: keeps the (hundreds of) loop-invariant weight addresses
         // from being hoisted out of the tile loop and held in registers across it
@@ -812,30 +826,45 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             D2_TICK(1);
         } else {
             (void)n;
-            const float* rhp = d.sv_rh + (size_t)n_row * W;
+            // (sixteen 16-byte loads of the saved relu(hidden) row used to be spilled one by one here: sixteen serialised
+            // HBM round trips per tile; the forward now leaves the bits behind in this lane layout)
+            const uint4 hm = reinterpret_cast<const uint4*>(d.sv_hmask)[(size_t)tile * 64 + lane];
+            const uint32_t hmw[4] = {hm.x, hm.y, hm.z, hm.w};
 #pragma unroll
-            for (int t = 0; t < WT; t++) hidmask[t] = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const AVec<WT> v = ldv<WT>(rhp + WT * rho(r, h));
-#pragma unroll
-                for (int t = 0; t < WT; t++) hidmask[t] |= (v.v[t] > 0.f ? 1u : 0u) << r;
-            }
+            for (int t = 0; t < WT; t++) hidmask[t] = hmw[t];
         }
         // SAVED: the relu(h1) tile of the NEXT head to process is fetched one head ahead (64 registers), under the long
         // transposed product of the current one -- the kernel is otherwise HBM-latency bound on these 16-KB tiles
         // (sixteen named registers quadruples, not an array: an array carried across the head loop is "promoted" to LDS by
         // the compiler's alloca pass instead of being scalarised)
-#define FDGS_TV_LIST(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
-#define FDGS_TV_DECL(j) float4 tv##j = make_float4(0.f, 0.f, 0.f, 0.f);
-        FDGS_TV_LIST(FDGS_TV_DECL)
 #define FDGS_TV_LOAD(j) if (j < WT * 4) tv##j = tsrc[j * 64 + lane];
 #define FDGS_TV_STORE(j) if (j < WT * 4) { const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4); \
                                           *reinterpret_cast<float4*>(lds + row * STRIDE + 4 * c4) = tv##j; }
         if constexpr (SAVED) {
-            const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[hd] * d.s.Npad + n0) * W);
-            FDGS_TV_LIST(FDGS_TV_LOAD)
+            if (!tv_loaded) {
+                const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[hd] * d.s.Npad + n0) * W);
+                FDGS_TV_LIST(FDGS_TV_LOAD)
+            }
         }
+        // SAVED: request the relu(h1) rows that are needed NEXT (next head of this tile, or the first head of this wave's
+        // next tile) as soon as the 64 staging registers are free, i.e. right after they were copied to LDS -- a whole head
+        // iteration ahead.  (Requested just before B1.run they sat in front of B1's operand ring in the in-order load
+        // queue and every head paid their HBM latency at its first MFMA: 21 k instead of 18 k cycles per head.)
+        auto request_next_rows = [&](int cur_hd) {
+            if constexpr (SAVED) {
+                int nx = next_head(p.head_on, cur_hd);
+                int nn0 = n0;
+                const bool wrap = nx >= FDGS_NUM_HEADS;
+                if (wrap) { nx = next_head(p.head_on, -1); nn0 = n0 + gridDim.x * 4 * 32; }
+                const bool have = nn0 < d.ntiles * 32;
+                tv_loaded = have && wrap;   // "this wave's next tile finds its first rows already requested"
+                if (have) {
+                    const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[nx] * d.s.Npad + nn0) * W);
+                    FDGS_TV_LIST(FDGS_TV_LOAD)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
 #pragma unroll
         for (int t = 0; t < WT; t++) dhid[t] = zero16();
         const float* Grow = d.s.G + (size_t)n_row * GCOLS;
@@ -899,21 +928,24 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #pragma unroll
                     for (int t = 0; t < WT; t++) mask[t] |= (v.v[t] > 0.f ? 1u : 0u) << r;
                 }
+                if (!(!small && k > 32)) request_next_rows(hd);   // (the cooperative SH block needs the registers first)
                 D2_TICK(2);
             }
             DenseT<WT, WT, true, 4> B1;
             const float* w2p = p.w2[hd] + WT * g;
             const int nsteps = (k + 1) >> 1;
             auto ldA = [&](int s) { int o = 2 * s + h; o = o < k ? o : k - 1; return ldv<WT>(w2p + (size_t)o * W); };
-            auto ldB = [&](int s) { const int o = 2 * s + h; const float v = Grow[off + o]; return o < k ? v : 0.f; };
+            // (raw loads: the o < k select is applied where the value is consumed -- a select next to the request would wait
+            // for it, and with the next tile rows queued in front of it that wait is an HBM round trip)
+            auto ldB = [&](int s) { return Grow[off + 2 * s + h]; };
+            auto selB = [&](float v, int s) { return 2 * s + h < k ? v : 0.f; };
             AVec<WT> a0, a1, a2;
             float b0, b1, b2;
             auto early_requests = [&]() {
                 B1.setup(p.w1[hd], W, W, g, h);
                 B1.preload();
                 a0 = ldA(0); a1 = ldA(1 < nsteps ? 1 : 0); a2 = ldA(2 < nsteps ? 2 : 0);
-                b0 = ldB(0); b1 = ldB(1 < nsteps ? 1 : 0); b2 = ldB(2 < nsteps ? 2 : 0);
-                b1 = 1 < nsteps ? b1 : 0.f; b2 = 2 < nsteps ? b2 : 0.f;
+                b0 = ldB(0); b1 = ldB(1 < nsteps ? 1 : 0); b2 = ldB(2 < nsteps ? 2 : 0);   // steps >= nsteps are never consumed
             };
             const bool coop = !small && k > 32;
             if (!coop) early_requests();   // (the cooperative SH block needs the registers: requests follow it)
@@ -974,6 +1006,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                     }
                 }
                 tiles_shared = true;
+                request_next_rows(hd);
                 early_requests();
             }
             for (int ot2 = 0; ot2 < ((small || coop) ? 0 : nt2); ot2++) {
@@ -1028,7 +1061,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #pragma unroll
                 for (int s = 0; s < NSH; s++) {
                     const AVec<WT> a = ra[s % PDH];
-                    const float b = rb[s % PDH];
+                    const float b = selB(rb[s % PDH], s);
                     if (s + PDH < NSH) { ra[s % PDH] = ldA(s + PDH); rb[s % PDH] = ldB(s + PDH); }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1037,7 +1070,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             } else {
                 for (int s = 0; s < nsteps; s++) {
                     const AVec<WT> a = a0;
-                    const float b = b0;
+                    const float b = selB(b0, s);
                     a0 = a1; b0 = b1; a1 = a2; b1 = b2;
                     if (s + 3 < nsteps) { a2 = ldA(s + 3); b2 = ldB(s + 3); }
 #pragma unroll
@@ -1054,14 +1087,6 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             if (!tiles_shared) store_tile_coalesced<WT>(lds, slab + (size_t)n0 * W, dh1, g, h, lane);
             else store_il<WT>(slab + (size_t)n_row * W, dh1, h);
             D2_TICK(6);
-            if constexpr (SAVED) {
-                const int nx = next_head(p.head_on, hd);
-                if (nx < FDGS_NUM_HEADS) {
-                    const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[nx] * d.s.Npad + n0) * W);
-                    FDGS_TV_LIST(FDGS_TV_LOAD)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             // ---- dhid += W1^T dh1
             B1.run(dh1, dhid);
             __builtin_amdgcn_wave_barrier();
@@ -1518,13 +1543,14 @@ static int active_heads(const fdgs_deform_params* p) {
     return c;
 }
 // activations the forward can leave behind for the backward (float offsets into the `saved` buffer)
-struct SavedLayout { size_t Np, feat, rh, h1, floats; };
+struct SavedLayout { size_t Np, feat, rh, h1, hmask, floats; };
 static SavedLayout saved_layout(const fdgs_deform_params* p) {
     SavedLayout s;
     s.Np = npad_of(p->N);
     const size_t F = (size_t)p->C * p->L, W = p->W;
     s.feat = 0; s.rh = s.feat + s.Np * F; s.h1 = s.rh + s.Np * W;
-    s.floats = s.h1 + s.Np * W * active_heads(p);
+    s.hmask = s.h1 + s.Np * W * active_heads(p);
+    s.floats = s.hmask + s.Np * 8;   // 64 lanes x 4 words per 32 Gaussians
     return s;
 }
 
@@ -1544,6 +1570,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         const SavedLayout sl = saved_layout(p);
         float* sv = reinterpret_cast<float*>(out->saved);
         d.sv_feat = sv ? sv + sl.feat : nullptr; d.sv_rh = sv ? sv + sl.rh : nullptr; d.sv_h1 = sv ? sv + sl.h1 : nullptr;
+        d.sv_hmask = sv ? reinterpret_cast<uint32_t*>(sv + sl.hmask) : nullptr;
         d.Npad = (int)sl.Np;
         int slot = 0;
         for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) d.head_slot[hd] = p->head_on[hd] ? slot++ : 0;
@@ -1613,11 +1640,11 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     bd.p = *p; bd.sc = aabb_scale(p); bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
     const float* X_rh = s.RH;      // operands of the weight-gradient GEMMs: recomputed into scratch, or saved by the forward
     const float* X_feat = s.FEAT;
-    bd.sv_rh = bd.sv_h1 = nullptr;
+    bd.sv_rh = bd.sv_h1 = nullptr; bd.sv_hmask = nullptr;
     if (g->saved && tunable("FDGS_USE_SAVED", 1)) {
         const SavedLayout sl = saved_layout(p);
         const float* sv = reinterpret_cast<const float*>(g->saved);
-        bd.sv_rh = sv + sl.rh; bd.sv_h1 = sv + sl.h1;
+        bd.sv_rh = sv + sl.rh; bd.sv_h1 = sv + sl.h1; bd.sv_hmask = reinterpret_cast<const uint32_t*>(sv + sl.hmask);
         X_rh = sv + sl.rh; X_feat = sv + sl.feat;
     }
     int slot = 0;
