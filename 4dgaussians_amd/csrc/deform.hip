@@ -111,8 +111,12 @@ struct DeformDev {
 // 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian.
 // Texel addresses are 32-bit byte offsets from the (wave-uniform) plane pointer: one VALU op per address and the
 // SGPR-base + VGPR-offset load form, instead of 64-bit multiply-adds per corner (planes are < 2^32 bytes by validation).
-__device__ __forceinline__ float4 gather_chunk(const fdgs_deform_params& p, int f0, const float* q) {
-    const int lvl = f0 / p.C, c0 = f0 - lvl * p.C;
+// The level index is the same for both lane halves (C % 8 == 0): computed from the wave-uniform chunk index and pinned
+// to an SGPR, so that the resolutions and plane pointers are scalar (kernarg) loads.  (Derived from the per-lane f0 they
+// were two dependent VECTOR loads per chunk, each a full memory round trip in front of the 24 texel requests.)
+__device__ __forceinline__ float4 gather_chunk(const fdgs_deform_params& p, int j, int h, const float* q) {
+    const int lvl = __builtin_amdgcn_readfirstlane((8 * j) / p.C);
+    const int c0 = 8 * j + 4 * h - lvl * p.C;
     float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -149,7 +153,7 @@ template <int FCH>
 __device__ __forceinline__ void gather_features(const fdgs_deform_params& p, const float* q, int h, f32x16* feat) {
 #pragma unroll
     for (int j = 0; j < FCH; j++) {
-        const float4 v = gather_chunk(p, 8 * j + 4 * h, q);
+        const float4 v = gather_chunk(p, j, h, q);
         feat[j / 4][4 * (j % 4) + 0] = v.x; feat[j / 4][4 * (j % 4) + 1] = v.y;
         feat[j / 4][4 * (j % 4) + 2] = v.z; feat[j / 4][4 * (j % 4) + 3] = v.w;
     }
