@@ -256,14 +256,42 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
 // One workgroup per 256 consecutive depth-sorted Gaussians; every lane then walks the workgroup's pair range with a
 // stride of 256 and finds the owning Gaussian by an 8-step binary search in LDS, so the pair stream is written
 // fully coalesced.
+// With exact tile culling (gs_math.h) a Gaussian's pairs are the SET bits of its 256-bit tile mask, in bit order: local
+// pair index -> position of the local-th set bit (squares of more than 256 tiles are not culled and keep the direct map).
+__device__ __forceinline__ uint32_t nth_set_bit(const uint4 lo, const uint4 hi, uint32_t n) {
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t base = 0, word = w[0];
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const uint32_t c = (uint32_t)__popc(word);
+        const bool next = n >= c && base == 32u * q;   // still walking: skip this word
+        n = next ? n - c : n;
+        word = next ? w[q + 1] : word;
+        base = next ? base + 32u : base;
+    }
+    uint32_t pos = 0;
+#pragma unroll
+    for (int sh = 16; sh > 0; sh >>= 1) {
+        const uint32_t c = (uint32_t)__popc(word & ((1u << sh) - 1u));
+        const bool up = n >= c;
+        n = up ? n - c : n;
+        word = up ? word >> sh : word;
+        pos = up ? pos + sh : pos;
+    }
+    return base + pos;
+}
+
 __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t* __restrict__ sorted_ids,
                                                            const uint32_t* __restrict__ offsets_incl,
                                                            const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect,
+                                                           const uint4* __restrict__ cullmask, const uint32_t* __restrict__ total,
                                                            int gx, uint32_t* __restrict__ pair_tile,
                                                            uint32_t* __restrict__ pair_gid) {
     __shared__ uint32_t s_end[256];
     __shared__ uint32_t s_gid[256];
     __shared__ uint2 s_rect[256];
+    __shared__ uint4 s_mask[256][2];
+    const bool culled = total[2] != 0;
     const int t = threadIdx.x;
     const int i = blockIdx.x * 256 + t;
     uint32_t gid = 0, end = 0, cnt = 0;
@@ -273,6 +301,7 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
         end = offsets_incl[i];
         cnt = tiles[gid];
         rc = rect[gid];
+        if (culled && cnt) { s_mask[threadIdx.x][0] = cullmask[2 * (size_t)gid]; s_mask[threadIdx.x][1] = cullmask[2 * (size_t)gid + 1]; }
     } else {
         end = offsets_incl[P - 1];
     }
@@ -295,7 +324,8 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
         const uint32_t xmin = r.x & 0xFFFFu, ymin = r.x >> 16, xmax = r.y & 0xFFFFu;
         const uint32_t w = xmax - xmin;
         const uint32_t jstart = (j == 0) ? start : s_end[j - 1];
-        const uint32_t local = p - jstart;
+        uint32_t local = p - jstart;
+        if (culled && w * ((r.y >> 16) - ymin) <= 256u) local = nth_set_bit(s_mask[j][0], s_mask[j][1], local);
         const uint32_t ty = ymin + local / w, tx = xmin + local % w;
         pair_tile[p] = ty * (uint32_t)gx + tx;
         pair_gid[p] = s_gid[j];
@@ -389,7 +419,8 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
     { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
-                       at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), il.gx,
+                       at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
+                       at<uint32_t>(geom, gl.total), il.gx,
                        at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0)); }
     FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
     int in = 0;
@@ -416,7 +447,7 @@ extern "C" int fdgs_geom_field(void* geom, int P, int which, void** ptr) {
     switch (which) {
         case 0: off = gl.depth; break; case 1: off = gl.recA; break; case 2: off = gl.recB; break; case 3: off = gl.recC; break;
         case 4: off = gl.cov3D; break; case 5: off = gl.tiles; break; case 6: off = gl.clamped; break; case 7: off = gl.rect; break;
-        case 8: off = gl.ids0; break; case 9: off = gl.offsets; break;
+        case 8: off = gl.ids0; break; case 9: off = gl.offsets; break; case 10: off = gl.cullmask; break;
         default: return fail(FDGS_E_INVALID, "%s", "unknown geom field");
     }
     *ptr = at<char>(geom, off);

@@ -84,7 +84,7 @@ constexpr int RADIX = 1 << RADIX_BITS;
 
 // ---- geom buffer layout (struct of arrays, 256-B aligned sections) ----
 struct GeomLayout {
-    size_t depth, recA, recB, recC, cov3D, tiles, clamped, rect, keys0, keys1, ids0, ids1, offsets, hist, total, bytes;
+    size_t depth, recA, recB, recC, cov3D, tiles, clamped, rect, keys0, keys1, ids0, ids1, offsets, hist, total, cullmask, bytes;
     int sort_blocks;
 };
 inline GeomLayout geom_layout(int P) {
@@ -92,7 +92,7 @@ inline GeomLayout geom_layout(int P) {
     size_t o = 0;
     size_t n = (size_t)(P > 0 ? P : 1);
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
-    g.total = take(256);  // [0] = total tiles touched (u32), [1] = scan carry scratch
+    g.total = take(256);  // [0] = total tiles touched (u32), [1] = scan carry scratch, [2] = 1 when tiles were culled
     g.depth = take(n * 4);
     g.recA = take(n * 16);
     g.recB = take(n * 16);
@@ -106,6 +106,7 @@ inline GeomLayout geom_layout(int P) {
     g.ids0 = take(n * 4);
     g.ids1 = take(n * 4);
     g.offsets = take(n * 4);
+    g.cullmask = take(n * 32);   // 256 bits per Gaussian: which tiles of its square can receive a contribution
     g.sort_blocks = cdiv((long long)n, SORT_CHUNK);
     g.hist = take(((size_t)RADIX * g.sort_blocks + 1024) * 4);
     g.bytes = o;

@@ -152,6 +152,60 @@ FDGS_HD bool project_gaussian(const CamConst& c, const float* p, const float* c6
     return true;
 }
 
+// ---- exact tile culling ------------------------------------------------------------------------------------------
+// The reference lists a Gaussian for every tile of the bounding square of its 3-sigma circle (Appendix B.1/B.2), but a
+// pixel only blends it when alpha = min(0.99, opacity * exp(-q)) >= 1/255, q(d) = 0.5 (a dx^2 + c dy^2) + b dx dy, i.e.
+// inside the ellipse q <= ln(255 * opacity).  A (Gaussian, tile) pair whose tile rectangle misses that ellipse changes
+// neither T nor any accumulator of any pixel, forward or backward: dropping it leaves every output bit-identical and
+// removes it from the sort and from both blending kernels.  The test is conservative: the ellipse is grown by a margin
+// far above the rounding of the per-pixel evaluation, the tile is treated as a continuous rectangle, and anything
+// numerically odd (non-positive-definite conic, NaN) keeps the reference's full list.
+struct CullEllipse {
+    float a, b, c, t2a, det, X, Y;   // q-ellipse, 2*a*t, a*c - b^2, half extents along x and y
+    int mode;                        // 0: no pixel can pass, 1: test rows, 2: keep every tile of the square
+};
+FDGS_HD CullEllipse cull_setup(const float* conic, float opacity) {
+    CullEllipse E;
+    E.a = conic[0]; E.b = conic[1]; E.c = conic[2];
+    E.det = E.a * E.c - E.b * E.b;
+    E.mode = 2; E.t2a = 0.f; E.X = 0.f; E.Y = 0.f;
+    if (!(opacity > 0.0f)) { E.mode = 0; return E; }          // alpha <= 0 < 1/255 everywhere
+    if (!(E.a > 0.0f && E.c > 0.0f && E.det > 0.0f)) return E;
+    float t = logf(255.0f * opacity);
+    t = t + 1e-3f + 1e-3f * fabsf(t);                          // alpha threshold lowered by > 0.1 %
+    if (!(t == t)) return E;
+    if (t < 0.0f) { E.mode = 0; return E; }
+    E.t2a = 2.0f * E.a * t;
+    E.X = sqrtf(2.0f * t * E.c / E.det);
+    E.Y = sqrtf(2.0f * t * E.a / E.det);
+    if (!(E.X == E.X && E.Y == E.Y) || E.X > 1e8f || E.Y > 1e8f) return E;
+    E.mode = 1;
+    return E;
+}
+// Tiles [*txlo, *txhi] (inclusive, not clamped to the image) of tile row ty that the ellipse may reach; false when none.
+// (px, py) = Gaussian centre in pixel coordinates; pixel centres sit at integer coordinates.
+FDGS_HD bool cull_row(const CullEllipse& E, float px, float py, int ty, int* txlo, int* txhi) {
+    const float y0 = (float)(ty * FDGS_TILE) - py, y1 = y0 + (float)(FDGS_TILE - 1);
+    const float eps = 0.02f + 1e-5f * (E.X + E.Y);
+    const float yl = fmaxf(y0, -E.Y - eps), yh = fminf(y1, E.Y + eps);
+    if (yl > yh) return false;
+    // x-range of the ellipse over the band: extreme points (+-X at dy = -+b X / c) when they lie in the band, else the ends
+    const float dyR = -E.b * E.X / E.c;
+    const float sl = sqrtf(fmaxf(0.0f, E.t2a - E.det * yl * yl)), sh = sqrtf(fmaxf(0.0f, E.t2a - E.det * yh * yh));
+    const float inv_a = 1.0f / E.a;
+    float hi = fmaxf((-E.b * yl + sl) * inv_a, (-E.b * yh + sh) * inv_a);
+    float lo = fminf((-E.b * yl - sl) * inv_a, (-E.b * yh - sh) * inv_a);
+    if (dyR >= yl && dyR <= yh) hi = E.X;
+    if (-dyR >= yl && -dyR <= yh) lo = -E.X;
+    lo -= eps; hi += eps;
+    if (!(lo <= hi)) { *txlo = -(1 << 20); *txhi = 1 << 20; return true; }   // NaN: keep the row
+    // smallest tx with 16 tx + 15 - px >= lo  <=>  tx >= (lo + px - 15) / 16
+    *txlo = (int)ceilf((lo + px - (float)(FDGS_TILE - 1)) / (float)FDGS_TILE);
+    // largest tx with 16 tx - px <= hi
+    *txhi = (int)floorf((hi + px) / (float)FDGS_TILE);
+    return *txlo <= *txhi;
+}
+
 FDGS_HD void sh_basis(int deg, float x, float y, float z, float* b) {
     b[0] = FDGS_SH_C0;
     if (deg > 0) {

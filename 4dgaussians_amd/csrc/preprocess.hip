@@ -29,6 +29,7 @@ struct PreFwdArgs {
     float* depth; float4 *recA, *recB, *recC; float* cov3D;
     uint32_t *tiles, *clamped; uint2* rect; uint32_t *keys, *ids, *total;
     int32_t* radii;
+    int cull; uint4* cullmask;   // exact tile culling (gs_math.h): 256-bit tile mask per Gaussian, two uint4 each
 };
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -89,6 +90,35 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
             a.rect[i] = make_uint2(g.rect_min, g.rect_max);
             radius = g.radius;
             my_tiles = (uint32_t)g.tiles;
+            if (a.cull && g.tiles <= 256) {
+                // which tiles of the 3-sigma square can receive a contribution at all: bit (ty - y0) * w + (tx - x0)
+                const int rx0 = (int)(g.rect_min & 0xFFFFu), ry0 = (int)(g.rect_min >> 16);
+                const int rx1 = (int)(g.rect_max & 0xFFFFu), ry1 = (int)(g.rect_max >> 16), w = rx1 - rx0;
+                unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
+                const CullEllipse E = cull_setup(g.conic, a.opacities[i]);
+                uint32_t cnt = 0;
+                if (E.mode != 0) {
+                    for (int ty = ry0; ty < ry1; ty++) {
+                        int lo = rx0, hi = rx1 - 1;
+                        if (E.mode == 1) {
+                            int tl, th;
+                            if (!cull_row(E, g.px, g.py, ty, &tl, &th)) continue;
+                            lo = tl > lo ? tl : lo; hi = th < hi ? th : hi;
+                            if (lo > hi) continue;
+                        }
+                        const int s0 = (ty - ry0) * w + (lo - rx0), s1 = s0 + (hi - lo);
+                        cnt += (uint32_t)(hi - lo + 1);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int s = s0 > 64 * q ? s0 : 64 * q, e = s1 < 64 * q + 63 ? s1 : 64 * q + 63;
+                            if (s <= e) m[q] |= (~0ull >> (63 - (e - s))) << (s - 64 * q);
+                        }
+                    }
+                }
+                my_tiles = cnt;
+                a.cullmask[2 * (size_t)i] = make_uint4((uint32_t)m[0], (uint32_t)(m[0] >> 32), (uint32_t)m[1], (uint32_t)(m[1] >> 32));
+                a.cullmask[2 * (size_t)i + 1] = make_uint4((uint32_t)m[2], (uint32_t)(m[2] >> 32), (uint32_t)m[3], (uint32_t)(m[3] >> 32));
+            }
             key = __float_as_uint(g.depth);  // depth > 0.2: the raw bits order like the value
         }
         a.tiles[i] = my_tiles;
@@ -98,6 +128,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
     }
     uint32_t s = wave_sum_u32(my_tiles);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.total, s);
+    if (i == 0) a.total[2] = a.cull ? 1u : 0u;   // the pair expansion reads which list semantics the counts have
 }
 
 struct PreBwdArgs {
@@ -252,6 +283,7 @@ extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, v
     a.recC = at<float4>(geom, gl.recC); a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles);
     a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
     a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii;
+    a.cull = tunable("FDGS_TILE_CULL", 1) != 0; a.cullmask = at<uint4>(geom, gl.cullmask);
     { FDGS_TIMED("preprocess_fwd", stream); hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
     return FDGS_OK;

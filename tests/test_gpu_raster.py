@@ -86,8 +86,38 @@ CASES = [
 ]
 
 
+def _culled_pairs_contribute_nothing(o, listed_gid, listed_tile, ok, W, H):
+    """Every (Gaussian, tile) pair of the reference's list (all tiles of the 3-sigma square) that the device list lacks must
+    be unable to reach alpha >= 1/255 on any pixel of the tile (float64 re-evaluation of the per-pixel rule, Appendix B.3)."""
+    gx = (W + 15) // 16
+    rect = o.field("rect").astype(np.int64)
+    co = o.field("conic_opacity").astype(np.float64)
+    xy = o.field("xy").astype(np.float64)
+    have = set(zip(listed_gid.tolist(), listed_tile.tolist()))
+    miss_g, miss_t = [], []
+    for gi in np.nonzero(ok)[0]:
+        x0, y0, x1, y1 = rect[gi]
+        for ty in range(y0, y1):
+            for tx in range(x0, x1):
+                if (gi, ty * gx + tx) not in have:
+                    miss_g.append(gi); miss_t.append(ty * gx + tx)
+    if not miss_g:
+        return 0
+    g, t = np.array(miss_g), np.array(miss_t)
+    px = ((t % gx) * 16)[:, None, None] + np.arange(16)[None, None, :]
+    py = ((t // gx) * 16)[:, None, None] + np.arange(16)[None, :, None]
+    dx, dy = xy[g, 0][:, None, None] - px, xy[g, 1][:, None, None] - py
+    power = -0.5 * (co[g, 0][:, None, None] * dx * dx + co[g, 2][:, None, None] * dy * dy) - co[g, 1][:, None, None] * dx * dy
+    alpha = co[g, 3][:, None, None] * np.exp(np.minimum(power, 0))
+    live = (power <= 0) & (alpha >= 1.0 / 255) & (px < W) & (py < H)
+    assert not live.any(), f"{int(live.reshape(len(g), -1).any(1).sum())} culled pairs have contributing pixels"
+    return len(g)
+
+
+@pytest.mark.parametrize("cull", [False, True])
 @pytest.mark.parametrize("case", CASES)
-def test_stagewise_forward_parity(case):
+def test_stagewise_forward_parity(case, cull, monkeypatch):
+    monkeypatch.setenv("FDGS_TILE_CULL", "1" if cull else "0")
     dev = torch.device("cuda:0")
     sc = raster_scene(**case)
     o = RasterOracle(**sc)
@@ -103,7 +133,10 @@ def test_stagewise_forward_parity(case):
     recB = _geom(st, 2, (P, 4), torch.float32, dev)
     recC = _geom(st, 3, (P, 4), torch.float32, dev)
     tiles = _geom(st, 5, (P,), torch.int32, dev)
-    assert np.array_equal(tiles[ok], o.field("tiles_touched")[ok])
+    if cull:    # exact tile culling: a subset of the reference's list ...
+        assert np.all(tiles[ok] <= o.field("tiles_touched")[ok])
+    else:       # ... or the reference's list itself
+        assert np.array_equal(tiles[ok], o.field("tiles_touched")[ok])
     np.testing.assert_allclose(recA[ok, :2], o.field("xy")[ok], rtol=0, atol=2e-3)
     co = o.field("conic_opacity")
     assert rel_l2(recA[ok, 2:4], co[ok, 0:2]) < 1e-5 and rel_l2(recB[ok, 0], co[ok, 2]) < 1e-5
@@ -126,6 +159,10 @@ def test_stagewise_forward_parity(case):
     assert np.all((tx >= (rect[gid, 0] & 0xFFFF)) & (tx < (rect[gid, 1] & 0xFFFF)) & (ty >= (rect[gid, 0] >> 16)) & (ty < (rect[gid, 1] >> 16)))
     cnt = np.bincount(gid, minlength=P)
     assert np.array_equal(cnt, tiles)
+    if cull and P <= 5000:   # ... whose missing pairs cannot contribute to any pixel (brute force, small scenes)
+        dropped = _culled_pairs_contribute_nothing(o, gid, tile, ok, W, H)
+        print(f"[{case}] culled {dropped} of {int(o.field('tiles_touched')[ok].sum())} pairs")
+        assert dropped > 0 or case.get("scale_boost", 1.0) >= 10.0      # (screen-filling splats reach every tile)
     ranges = _img(st, 2, (gx * ((H + 15) // 16), 2), torch.int32, dev).view(np.uint32)
     tc = np.bincount(tile, minlength=ranges.shape[0])
     assert np.array_equal(ranges[:, 1] - ranges[:, 0], tc)
@@ -142,7 +179,10 @@ def test_stagewise_forward_parity(case):
     assert dd.mean() < 2e-5 and np.quantile(dd, 0.9999) < 5e-4
     fT, nc = o.image_state()
     nc_g = _img(st, 1, (H, W), torch.int32, dev)
-    assert (nc_g != nc.astype(np.int32)).mean() < 1e-3
+    if not cull:   # (n_contrib is a position in the pair list: only comparable when the lists are the reference's)
+        assert (nc_g != nc.astype(np.int32)).mean() < 1e-3
+    else:
+        assert np.all(nc_g <= nc.astype(np.int32) + 1)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -236,7 +276,7 @@ def test_full_size_properties_config4_shape():
     P = st.params.P
     tiles = _geom(st, 5, (P,), torch.int32, dev)
     assert st.num_rendered == int(tiles.astype(np.int64).sum())
-    assert np.array_equal(tiles > 0, radii.cpu().numpy() > 0)
+    assert not np.any((tiles > 0) & (radii.cpu().numpy() <= 0))      # (culling may leave a visible Gaussian without tiles)
     gid, tile = _binning(st, 0, dev), _binning(st, 1, dev)
     recB = _geom(st, 2, (P, 4), torch.float32, dev)
     key = (tile.astype(np.uint64) << np.uint64(32)) | recB[:, 2].view(np.uint32)[gid].astype(np.uint64)
@@ -254,3 +294,31 @@ def test_full_size_properties_config4_shape():
         sc_p[k] = np.ascontiguousarray(sc[k][perm])
     (color3, _, _, _), _ = _run_forward(sc_p, dev)
     assert (color3 - color).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_tile_culling_is_exact(case, monkeypatch):
+    """Forward outputs with and without exact tile culling are BIT-identical (a dropped pair never touches T or an
+    accumulator); backward gradients agree to atomic-ordering noise; the pair list shrinks."""
+    dev = torch.device("cuda:0")
+    sc = raster_scene(**case)
+    R = _mod().rasterizer
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FDGS_TILE_CULL", flag)
+        t = {k: torch.tensor(sc[k], device=dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2d = torch.zeros(t["means3D"].shape[0], 3, device=dev, requires_grad=True)
+        color, radii, depth = R.GaussianRasterizer(_settings(sc, dev))(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                                                                    scales=t["scales"], rotations=t["rotations"])
+        gen = torch.Generator().manual_seed(1)
+        w = torch.randn(color.shape, generator=gen).to(dev)
+        (color * w).sum().backward()
+        (_, _, _, st), _ = _run_forward(sc, dev)
+        outs.append((color.detach(), radii, depth.detach(), {k: v.grad.clone() for k, v in t.items()}, m2d.grad.clone(), st.num_rendered))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert rel_l2(b[3][k].cpu().numpy(), a[3][k].cpu().numpy()) < 1e-5, k
+    assert rel_l2(b[4].cpu().numpy(), a[4].cpu().numpy()) < 1e-5
+    assert b[5] <= a[5] and (b[5] < a[5] or case.get("scale_boost", 1.0) >= 10.0)
+    print(f"[{case}] pairs {a[5]} -> {b[5]} ({100.0 * b[5] / a[5]:.1f} %)")
