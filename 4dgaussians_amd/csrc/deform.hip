@@ -1212,29 +1212,38 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
 #pragma unroll
         for (int b = 0; b < NB; b++) bbuf[s][b] = ldv<BV>(bp[b] + (size_t)ss * 2 * J.ldx);
     }
-    for (int s0 = 0; s0 < nsteps; s0 += WG_PD) {
+    // Full groups of WG_PD steps without any control flow inside: slot u is consumed, THEN refilled in place with step
+    // s + WG_PD.  (The first form copied the slot, refilled it and then ran the MFMAs under `if (s < nsteps)`; the register
+    // copies at the loop back-edge and the per-step branches made the wait-count pass put `vmcnt(0)` in front of the last
+    // MFMAs of EVERY step, i.e. each step waited for the loads it had just issued: 57 % MFMA utilisation, rocprofv3 r01h.)
+    auto consume = [&](int u) {
+#pragma unroll
+        for (int a = 0; a < WT; a++) asum[a] += abuf[u].v[a];
+#pragma unroll
+        for (int a = 0; a < WT; a++)
+#pragma unroll
+            for (int b = 0; b < CT; b++)
+                acc[a][b] = mfma32(abuf[u].v[a], COLS_IL ? bbuf[u][0].v[b] : bbuf[u][b].v[0], acc[a][b]);
+    };
+    const int ngroups = nsteps / WG_PD;
+    for (int gi = 0; gi < ngroups; gi++) {
 #pragma unroll
         for (int u = 0; u < WG_PD; u++) {
-            const int s = s0 + u;
-            if (s < nsteps) {
-                const AVec<WT> av = abuf[u];
-                AVec<BV> bv[NB];
+            consume(u);
+            __builtin_amdgcn_sched_barrier(0);
+            int sn = (gi + 1) * WG_PD + u;
+            sn = sn < nsteps ? sn : nsteps - 1;   // past the end: harmless re-load of a valid row, never consumed
+            abuf[u] = ldv<WT>(ap + (size_t)sn * 2 * W);
 #pragma unroll
-                for (int b = 0; b < NB; b++) bv[b] = bbuf[u][b];
-                const int sn = s + WG_PD < nsteps ? s + WG_PD : s;   // tail: harmless re-load of a valid row
-                abuf[u] = ldv<WT>(ap + (size_t)sn * 2 * W);
-#pragma unroll
-                for (int b = 0; b < NB; b++) bbuf[u][b] = ldv<BV>(bp[b] + (size_t)sn * 2 * J.ldx);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < WT; a++) asum[a] += av.v[a];
-#pragma unroll
-                for (int a = 0; a < WT; a++)
-#pragma unroll
-                    for (int b = 0; b < CT; b++) acc[a][b] = mfma32(av.v[a], COLS_IL ? bv[0].v[b] : bv[b].v[0], acc[a][b]);
-            }
+            for (int b = 0; b < NB; b++) bbuf[u][b] = ldv<BV>(bp[b] + (size_t)sn * 2 * J.ldx);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // remainder (< WG_PD steps): their rows are exactly what slots 0 .. rem-1 were refilled (or preloaded) with
+    const int rem = nsteps - ngroups * WG_PD;
+#pragma unroll
+    for (int u = 0; u < WG_PD; u++)
+        if (u < rem) consume(u);
     // workgroup reduction in LDS, ldsW[m * ldl + c] with ldl = 32*CT: the four waves take turns (barrier between turns) and
     // use plain stores / read-add-writes -- ds_add_f32 runs at 0.33 lanes/clk/CU on MI355X (tools/lds_atomic_bench.hip:
     // 37x slower than ds_add_u32, ~200x slower than plain LDS traffic) and 4 x 16 k float atomics cost ~15 % of this kernel
