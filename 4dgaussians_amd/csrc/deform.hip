@@ -1182,7 +1182,9 @@ constexpr int WG_PD = 6;
 
 // COLS_IL: X has exactly W columns, column mapping interleaved (vector loads); else tile mapping c = 32*b + j with
 // CT = ceil(ncols/32) dword loads per k-step (the small trunk product, ncols = C*L).
-template <int WT, int CT, bool COLS_IL>
+// PD = depth of the operand ring in k-steps: the narrow trunk products run only CT MFMAs per step, so they need a deeper
+// ring than the square head products to cover the same memory latency.
+template <int WT, int CT, bool COLS_IL, int PD>
 __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin, int n_end, float* ldsW, float* ldsB, int g, int h, int wave) {
     constexpr int BV = COLS_IL ? WT : 1, NB = COLS_IL ? 1 : CT;
     f32x16 acc[WT][CT];
@@ -1202,18 +1204,18 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
         bp[b] = J.X + (size_t)(n_begin + h) * J.ldx + col;
     }
     const int nsteps = (n_end - n_begin) >> 1;   // chunk lengths are even; 0 for a wave without work (it still joins the reduction)
-    AVec<WT> abuf[WG_PD];
-    AVec<BV> bbuf[WG_PD][NB];
+    AVec<WT> abuf[PD];
+    AVec<BV> bbuf[PD][NB];
 #pragma unroll
-    for (int s = 0; s < WG_PD; s++) {
+    for (int s = 0; s < PD; s++) {
         if (nsteps == 0) break;
         const int ss = s < nsteps ? s : 0;
         abuf[s] = ldv<WT>(ap + (size_t)ss * 2 * W);
 #pragma unroll
         for (int b = 0; b < NB; b++) bbuf[s][b] = ldv<BV>(bp[b] + (size_t)ss * 2 * J.ldx);
     }
-    // Full groups of WG_PD steps without any control flow inside: slot u is consumed, THEN refilled in place with step
-    // s + WG_PD.  (The first form copied the slot, refilled it and then ran the MFMAs under `if (s < nsteps)`; the register
+    // Full groups of PD steps without any control flow inside: slot u is consumed, THEN refilled in place with step
+    // s + PD.  (The first form copied the slot, refilled it and then ran the MFMAs under `if (s < nsteps)`; the register
     // copies at the loop back-edge and the per-step branches made the wait-count pass put `vmcnt(0)` in front of the last
     // MFMAs of EVERY step, i.e. each step waited for the loads it had just issued: 57 % MFMA utilisation, rocprofv3 r01h.)
     auto consume = [&](int u) {
@@ -1225,13 +1227,13 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
             for (int b = 0; b < CT; b++)
                 acc[a][b] = mfma32(abuf[u].v[a], COLS_IL ? bbuf[u][0].v[b] : bbuf[u][b].v[0], acc[a][b]);
     };
-    const int ngroups = nsteps / WG_PD;
+    const int ngroups = nsteps / PD;
     for (int gi = 0; gi < ngroups; gi++) {
 #pragma unroll
-        for (int u = 0; u < WG_PD; u++) {
+        for (int u = 0; u < PD; u++) {
             consume(u);
             __builtin_amdgcn_sched_barrier(0);
-            int sn = (gi + 1) * WG_PD + u;
+            int sn = (gi + 1) * PD + u;
             sn = sn < nsteps ? sn : nsteps - 1;   // past the end: harmless re-load of a valid row, never consumed
             abuf[u] = ldv<WT>(ap + (size_t)sn * 2 * W);
 #pragma unroll
@@ -1239,10 +1241,10 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // remainder (< WG_PD steps): their rows are exactly what slots 0 .. rem-1 were refilled (or preloaded) with
-    const int rem = nsteps - ngroups * WG_PD;
+    // remainder (< PD steps): their rows are exactly what slots 0 .. rem-1 were refilled (or preloaded) with
+    const int rem = nsteps - ngroups * PD;
 #pragma unroll
-    for (int u = 0; u < WG_PD; u++)
+    for (int u = 0; u < PD; u++)
         if (u < rem) consume(u);
     // workgroup reduction in LDS, ldsW[m * ldl + c] with ldl = 32*CT: the four waves take turns (barrier between turns) and
     // use plain stores / read-add-writes -- ds_add_f32 runs at 0.33 lanes/clk/CU on MI355X (tools/lds_atomic_bench.hip:
@@ -1308,11 +1310,11 @@ __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
     float* ldsB = lds + W * W;
     const int CTn = (J.ncols + 31) / 32;
     // (every wave joins, also one whose slice is empty: the reduction inside is a workgroup-wide protocol)
-    if (J.ncols == W) wgrad_wave<WT, WT, true>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 1) wgrad_wave<WT, 1, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 2) wgrad_wave<WT, 2, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 3) wgrad_wave<WT, 3, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if constexpr (WT != 4) wgrad_wave<WT, 4, false>(J, W, wb, we, ldsW, ldsB, g, h, wave);   // (W = 128, 128 columns) is the interleaved case
+    if (J.ncols == W) wgrad_wave<WT, WT, true, WG_PD>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 1) wgrad_wave<WT, 1, false, 16>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 2) wgrad_wave<WT, 2, false, 12>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 3) wgrad_wave<WT, 3, false, 8>(J, W, wb, we, ldsW, ldsB, g, h, wave);
+    else if constexpr (WT != 4) wgrad_wave<WT, 4, false, WG_PD>(J, W, wb, we, ldsW, ldsB, g, h, wave);   // (W = 128, 128 columns) is the interleaved case
     const int ldl = J.ncols == W ? W : 32 * CTn;
     for (int i = threadIdx.x; i < W * ldl; i += 256) {
         const int m = i / ldl, c = i - m * ldl;
@@ -1721,9 +1723,10 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int total_wgs = tunable("FDGS_WGRAD_WGS", cus);
         int work[FDGS_NUM_HEADS + 1], total_work = 0;
-        // cost model: MFMAs per k-step; the narrow trunk product (dword loads, only CT MFMAs per load pair) is
-        // load-latency bound, measured ~2.5x slower per MFMA than the square head products
-        const int trunk_factor = tunable("FDGS_WGRAD_TRUNK", 3);
+        // cost model: MFMAs per k-step; the narrow trunk product (dword loads, only CT MFMAs per load pair, deep ring) is
+        // memory-latency rather than MFMA bound: it costs about twice its MFMA count (sweep: 0.53 / 0.44 / 0.46 / 0.48 ms at
+        // factor 1 / 2 / 3 / 4)
+        const int trunk_factor = tunable("FDGS_WGRAD_TRUNK", 2);
         for (int j = 0; j < nj; j++) {
             work[j] = (wa.job[j].ncols + 31) / 32;
             if (wa.job[j].ncols != (int)W) work[j] *= trunk_factor;

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 
 SWEEPS = [
     ("default", {}),
+    ("wg_trunk=1", {"FDGS_WGRAD_TRUNK": "1"}),
     ("wg_trunk=2", {"FDGS_WGRAD_TRUNK": "2"}),
     ("wg_trunk=4", {"FDGS_WGRAD_TRUNK": "4"}),
     ("wg_trunk=6", {"FDGS_WGRAD_TRUNK": "6"}),
