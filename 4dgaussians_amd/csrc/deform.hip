@@ -25,8 +25,9 @@
 //      (scattered float atomics run at only ~20 G line-ops/s on MI355X: profiles/r01_atomic_microbench.txt); the three
 //      time planes are privatised in LDS.
 // Environment knobs (development / A-B only, defaults are the tuned values): FDGS_SMALL_HEADS, FDGS_USE_SAVED,
-// FDGS_D2_WGS, FDGS_WGRAD_WGS, FDGS_WGRAD_TRUNK, FDGS_PG_LDS, FDGS_PG_LDS_KB, FDGS_PG_WGS; -DFDGS_PROFILE_D2 adds an
-// in-kernel s_memtime phase profile of D2; -DFDGS_DEV_ONLY_44 builds only the (128, 32) instance.
+// FDGS_D1_WGS (0 = one workgroup per four tiles instead of the persistent tile loop), FDGS_D2_WGS, FDGS_WGRAD_WGS,
+// FDGS_WGRAD_TRUNK, FDGS_PG_LDS, FDGS_PG_LDS_KB, FDGS_PG_WGS; -DFDGS_PROFILE_D1 / -DFDGS_PROFILE_D2 add an in-kernel
+// s_memtime phase profile of D1 / D2 (printed once to stderr); -DFDGS_DEV_ONLY_44 builds only the (128, 32) instance.
 #include "common.h"
 
 #include <vector>
@@ -103,6 +104,8 @@ struct DeformDev {
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
     // optional saved activations for the backward (rows < Npad): features [Np][F], relu(hidden) [Np][W], relu(h1) [slot][Np][W]
     float *sv_feat, *sv_rh, *sv_h1;
+    int ntiles;                     // 32-Gaussian tiles (a multiple of 4)
+    unsigned long long* prof;       // development builds (-DFDGS_PROFILE_D1): cycle sums per phase
     uint32_t* sv_hmask;             // [Npad/32][64 lanes][4]: bit r of word t = relu(hidden) tile t register r > 0 (what D2's lane needs)
     int Npad;
     int head_slot[FDGS_NUM_HEADS];
@@ -148,14 +151,68 @@ __device__ __forceinline__ void load_query(const fdgs_deform_params& p, const Aa
     q[3] = p.time ? p.time[n] : p.time_scalar;
 }
 
+// Two adjacent chunks j0, j0+1 of ONE level (C >= 16: their channels are the two halves of the same 32 texel bytes): the
+// four axis samples and the texel offsets are computed once and all 48 texel requests are issued before the first one is
+// consumed -- one memory round trip for the pair.  (Chunk by chunk the four round trips of a 32-feature gather were 12 %
+// of D1 in its in-kernel cycle profile.)  Same arithmetic per chunk as gather_chunk.
+__device__ __forceinline__ void gather_chunk_pair(const fdgs_deform_params& p, int j0, int h, const float* q, float4& out0, float4& out1) {
+    const int lvl = __builtin_amdgcn_readfirstlane((8 * j0) / p.C);
+    const int c0 = 8 * j0 + 4 * h - lvl * p.C;
+    AxisSample S[4];
+#pragma unroll
+    for (int ax = 0; ax < 4; ax++) S[ax] = axis_sample(q[ax], p.res[lvl][ax]);
+    float4 v[6][4], u[6][4];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int a, b;
+        plane_axes(k, a, b);
+        const int Wd = p.res[lvl][a];
+        const AxisSample sx = S[a], sy = S[b];
+        const char* P = reinterpret_cast<const char*>(p.planes[lvl][k]);
+        const uint32_t texel = (uint32_t)p.C * 4u, cb = (uint32_t)c0 * 4u;
+        const uint32_t r0 = (uint32_t)(sy.i0 * Wd) * texel + cb, r1 = (uint32_t)(sy.i1 * Wd) * texel + cb;
+        const uint32_t x0 = (uint32_t)sx.i0 * texel, x1 = (uint32_t)sx.i1 * texel;
+        v[k][0] = *reinterpret_cast<const float4*>(P + (r0 + x0)); u[k][0] = *reinterpret_cast<const float4*>(P + (r0 + x0 + 32u));
+        v[k][1] = *reinterpret_cast<const float4*>(P + (r0 + x1)); u[k][1] = *reinterpret_cast<const float4*>(P + (r0 + x1 + 32u));
+        v[k][2] = *reinterpret_cast<const float4*>(P + (r1 + x0)); u[k][2] = *reinterpret_cast<const float4*>(P + (r1 + x0 + 32u));
+        v[k][3] = *reinterpret_cast<const float4*>(P + (r1 + x1)); u[k][3] = *reinterpret_cast<const float4*>(P + (r1 + x1 + 32u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    out0 = make_float4(1.f, 1.f, 1.f, 1.f); out1 = out0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int a, b;
+        plane_axes(k, a, b);
+        const AxisSample sx = S[a], sy = S[b];
+        const float w00 = sx.w0 * sy.w0, w01 = sx.w1 * sy.w0, w10 = sx.w0 * sy.w1, w11 = sx.w1 * sy.w1;
+        out0.x *= v[k][0].x * w00 + v[k][1].x * w01 + v[k][2].x * w10 + v[k][3].x * w11;
+        out0.y *= v[k][0].y * w00 + v[k][1].y * w01 + v[k][2].y * w10 + v[k][3].y * w11;
+        out0.z *= v[k][0].z * w00 + v[k][1].z * w01 + v[k][2].z * w10 + v[k][3].z * w11;
+        out0.w *= v[k][0].w * w00 + v[k][1].w * w01 + v[k][2].w * w10 + v[k][3].w * w11;
+        out1.x *= u[k][0].x * w00 + u[k][1].x * w01 + u[k][2].x * w10 + u[k][3].x * w11;
+        out1.y *= u[k][0].y * w00 + u[k][1].y * w01 + u[k][2].y * w10 + u[k][3].y * w11;
+        out1.z *= u[k][0].z * w00 + u[k][1].z * w01 + u[k][2].z * w10 + u[k][3].z * w11;
+        out1.w *= u[k][0].w * w00 + u[k][1].w * w01 + u[k][2].w * w10 + u[k][3].w * w11;
+    }
+}
+
 // features of lane (g,h): chunk j holds features 8j+4h .. +3 = registers 4(j%4)..+3 of tile j/4
 template <int FCH>
 __device__ __forceinline__ void gather_features(const fdgs_deform_params& p, const float* q, int h, f32x16* feat) {
-#pragma unroll
-    for (int j = 0; j < FCH; j++) {
-        const float4 v = gather_chunk(p, j, h, q);
+    auto put = [&](int j, const float4& v) {
         feat[j / 4][4 * (j % 4) + 0] = v.x; feat[j / 4][4 * (j % 4) + 1] = v.y;
         feat[j / 4][4 * (j % 4) + 2] = v.z; feat[j / 4][4 * (j % 4) + 3] = v.w;
+    };
+#pragma unroll
+    for (int j = 0; j < FCH; j += 2) {
+        if (j + 1 < FCH && (8 * j) / p.C == (8 * (j + 1)) / p.C) {   // (wave-uniform) both chunks in one level
+            float4 v0, v1;
+            gather_chunk_pair(p, j, h, q, v0, v1);
+            put(j, v0); put(j + 1, v1);
+        } else {
+            put(j, gather_chunk(p, j, h, q));
+            if (j + 1 < FCH) put(j + 1, gather_chunk(p, j + 1, h, q));
+        }
     }
 }
 
@@ -426,10 +483,23 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     const bool tunable_small = d.small_heads != 0;
     __shared__ __attribute__((aligned(16))) float fwd_lds[4 * 32 * (WT * 32 + 4)];   // staging tiles of the saved activations
     float* my_tile = fwd_lds + (threadIdx.x >> 6) * 32 * (WT * 32 + 4);
-    const size_t tile_n0 = (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;       // first Gaussian slot of this wave
     constexpr int FT = (FCH + 3) / 4;
-    const int lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
-    const int n_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + g;
+    const int lane = threadIdx.x & 63, g0 = lane & 31, h0 = lane >> 5;
+    // Every wave walks its own tiles (32 Gaussians each): nothing in the body synchronises the workgroup, so with
+    // gridDim.x = #CUs the kernel is persistent -- no workgroup relaunch between tiles and no SIMD waiting for the slowest
+    // of the four waves of its workgroup; with gridDim.x = ntiles / 4 the loop runs once (FDGS_D1_WGS selects).
+#ifdef FDGS_PROFILE_D1
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt = __builtin_amdgcn_s_memtime();
+#define D1_TICK(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[ph] += t_ - pt; pt = t_; } while (0)
+#else
+#define D1_TICK(ph) do { } while (0)
+#endif
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < d.ntiles; tile += gridDim.x * 4) {
+    int g = g0, h = h0;
+    asm volatile("" : "+v"(g), "+v"(h));   // keeps the per-layer weight addresses from being hoisted out of the tile loop
+    const size_t tile_n0 = (size_t)tile * 32;       // first Gaussian slot of this wave's tile
+    const int n_raw = tile * 32 + g;
     const bool live = n_raw < p.N;
     const int n = live ? n_raw : p.N - 1;
     const int W = WT * 32;
@@ -460,7 +530,9 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     f32x16 feat[FT];
 #pragma unroll
     for (int t = 0; t < FT; t++) feat[t] = zero16();
+    D1_TICK(0);
     gather_features<FCH>(p, q, h, feat);
+    D1_TICK(1);
     const size_t n_row = (size_t)n_raw;   // saved rows are indexed by the un-clamped Gaussian slot (< Npad)
     if (d.sv_feat) {
 #pragma unroll
@@ -548,6 +620,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
             if (!p.head_on[h0]) epilogue(h0, z, z);
     }
 
+    D1_TICK(2);
     while (hd < FDGS_NUM_HEADS) {
         const int k = head_k(hd);
         DenseIL<WT, 1, false, PD2> L2, L2b;
@@ -557,12 +630,14 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         L2.preload();
         f32x16 h1[WT];
         L1.run(hid, h1, h, drain_piece);
+        D1_TICK(3);
         relu_inplace<WT>(h1);
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
         if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head(p.head_on, hd);
         if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
         f32x16 o0 = zero16(), o1 = zero16();
+        D1_TICK(4);
         if (small) {
             const f32x4 o4 = L2.run4(h1);
             o0[0] = o4[0]; o0[1] = o4[1]; o0[2] = o4[2]; o0[3] = o4[3];
@@ -570,12 +645,22 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
             L2.run(h1, &o0, h);
         }
         if (k > 32) L2b.run(h1, &o1, h);
+        D1_TICK(5);
         epilogue(hd, o0, o1);
+        D1_TICK(6);
         hd = nxt;
     }
     // the last parked tile has no following layer to hide under
 #pragma unroll
     for (int j = 0; j < WT * 4; j++) drain_piece(j);
+    D1_TICK(7);
+    }   // tile loop
+#ifdef FDGS_PROFILE_D1
+    if (d.prof && lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], pacc[i]);
+        atomicAdd(&d.prof[8], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: prep
@@ -1592,7 +1677,35 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     }
     {
         FDGS_TIMED("deform_fwd", stream);
-        rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, cdiv(p->N, 128), d);
+        d.ntiles = 4 * cdiv(p->N, 128);
+        static int cus = 0;
+        if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
+        const int want = tunable("FDGS_D1_WGS", cus);     // 0: one workgroup per four tiles (not persistent)
+        const int wgs = want > 0 && want < d.ntiles / 4 ? want : d.ntiles / 4;
+        d.prof = nullptr;
+#ifdef FDGS_PROFILE_D1
+        static unsigned long long* prof_dev = nullptr;
+        if (!prof_dev) { (void)hipMalloc(&prof_dev, 16 * sizeof(unsigned long long)); }
+        (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
+        d.prof = prof_dev;
+#endif
+        rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+#ifdef FDGS_PROFILE_D1
+        {
+            static int reports = 0;
+            if (reports++ == 5) {
+                unsigned long long hb[16];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(hb, prof_dev, sizeof(hb), hipMemcpyDeviceToHost);
+                const char* names[8] = {"prologue (query, inputs, preloads)", "gather", "feat store + trunk + relu + park + hmask", "L1.run (+drains)",
+                                        "relu + park + next preloads", "L2 (+L2b)", "epilogue", "final drain"};
+                double tot = 0;
+                for (int i = 0; i < 8; i++) tot += (double)hb[i];
+                fprintf(stderr, "[D1 profile] %llu waves, cycles per wave:\n", hb[8]);
+                for (int i = 0; i < 8; i++) fprintf(stderr, "  %-44s %12.0f  (%.1f %%)\n", names[i], (double)hb[i] / (double)hb[8], 100.0 * hb[i] / tot);
+            }
+        }
+#endif
     }
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_fwd", 0, stream);
