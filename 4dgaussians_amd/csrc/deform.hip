@@ -1009,6 +1009,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 FDGS_TV_LIST(FDGS_TV_STORE)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                D2_TICK(0);
 #pragma unroll
                 for (int t = 0; t < WT; t++) mask[t] = 0;
 #pragma unroll
@@ -1056,7 +1057,9 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 else small_dw2(sw[3], sb[3]);
             }
             if (coop) {
+                D2_TICK(4);
                 __syncthreads();                                   // all four tiles of the workgroup are written
+                D2_TICK(1);
                 const int nwg0 = (tile - wave) * 32;               // first Gaussian of the workgroup's four tiles
 #pragma unroll
                 for (int j = 0; j < NU; j++) {
@@ -1095,8 +1098,10 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                     }
                 }
                 tiles_shared = true;
+                D2_TICK(10);
                 request_next_rows(hd);
                 early_requests();
+                D2_TICK(11);
             }
             for (int ot2 = 0; ot2 < ((small || coop) ? 0 : nt2); ot2++) {
                 const int o = ot2 * 32 + g;
@@ -1805,8 +1810,9 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
                 waves++;
                 for (int i = 0; i < 12; i++) sum[i] += (double)hbuf[w * 12 + i];
             }
-            const char* names[12] = {"gather+FEAT", "trunk+RH", "L1.run", "relu/mask/LDS+preloads", "dW2 flush", "dh1", "mask+DH1 store",
-                                     "B1.run", "tail(DHID,B0,DFEAT)", "wave total", "dW2 ga+asum", "dW2 mfma"};
+            const char* names[12] = {"saved: head top .. rows in LDS", "saved: SH barrier wait", "recompute: L1.run | saved: masks + next-row requests",
+                                     "operand preloads", "dW2 small heads (+ pre-barrier)", "dh1", "mask+DH1 store", "B1.run", "tail(DHID,B0,DFEAT)",
+                                     "wave total", "saved: SH cooperative block", "saved: SH requests after the block"};
             fprintf(stderr, "[D2 profile] %d waves, s_memtime ticks (100 MHz) per wave:\n", waves);
             for (int i = 0; i < 12; i++) fprintf(stderr, "  %-26s %12.0f  (%.1f %%)\n", names[i], sum[i] / waves, 100.0 * sum[i] / sum[9]);
         }
