@@ -41,10 +41,10 @@ def _f32(t):
     return t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous()
 
 
-def add_densification_stats(pc, viewspace_point_tensor_grad, update_filter, radii=None):
+def add_densification_stats(pc, viewspace_point_tensor, update_filter, radii=None):
     """xyz_gradient_accum[f] += |grad[f, :2]|, denom[f] += 1 (scene/gaussian_model.py:516-518) and, when `radii` is given,
     max_radii2D[f] = max(max_radii2D[f], radii[f]) (train.py:261), in place, without the host syncs of boolean indexing."""
-    g = viewspace_point_tensor_grad
+    g = viewspace_point_tensor          # (the reference passes the GRADIENT tensor under this name, train.py:262)
     if g.device.type != "cuda":
         raise _lib.FdgsError("the densification kernels run on the GPU only")
     g = _f32(g.detach())
