@@ -65,10 +65,11 @@ using namespace fdgs;
 extern "C" int fdgs_adam_step(void* stream_, int ntensors, const fdgs_adam_tensor* tensors, double beta1, double beta2, double eps) {
     FDGS_REQUIRE(ntensors >= 0 && (tensors || ntensors == 0), "bad tensor list");
     hipStream_t stream = (hipStream_t)stream_;
-    for (int base = 0; base < ntensors; base += ADAM_MAX_TENSORS) {
+    int i = 0;   // next input tensor: empty tensors are skipped without using a slot, so the consumed index is tracked
+    while (i < ntensors) {
         AdamArgs a{};
         int blocks = 0, cnt = 0;
-        for (int i = base; i < ntensors && cnt < ADAM_MAX_TENSORS; i++) {
+        for (; i < ntensors && cnt < ADAM_MAX_TENSORS; i++) {
             const fdgs_adam_tensor& s = tensors[i];
             if (s.n == 0) continue;
             FDGS_REQUIRE(s.param && s.grad && s.exp_avg && s.exp_avg_sq, "adam: NULL tensor pointer");

@@ -372,15 +372,16 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     if (p->P == 0) return FDGS_OK;
     GeomLayout gl = geom_layout(p->P);
     // the total was accumulated by preprocess: start its read-back now, sort while it is in flight
-    hipEvent_t ev;
-    FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // one event per host thread, created on first use and kept (the ABI contract is one host thread per stream)
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
     FDGS_HIP_CHECK(hipEventRecord(ev, stream));
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(geom, gl.keys0), at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.keys1),
                           at<uint32_t>(geom, gl.ids1), (uint32_t)p->P, 32, at<uint32_t>(geom, gl.hist), gl.sort_blocks, p->debug,
                           &in);
-    if (rc) { (void)hipEventDestroy(ev); return rc; }
+    if (rc) return rc;
     // 4 passes: result is back in buffer 0
     const uint32_t* sorted_ids = at<uint32_t>(geom, in ? gl.ids1 : gl.ids0);
     if (in != 0) {  // keep the contract "sorted ids live in ids0" for any pass count
@@ -398,10 +399,9 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     }
     {
         hipError_t e_ = hipGetLastError();
-        if (e_ != hipSuccess) { (void)hipEventDestroy(ev); return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }
+        if (e_ != hipSuccess) { return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }
     }
     hipError_t e = hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
     if (e != hipSuccess) return fail(FDGS_E_HIP, "%s failed: %s", "hipEventSynchronize", hipGetErrorString(e));
     if (p->debug) FDGS_HIP_CHECK(hipStreamSynchronize(stream));
     return FDGS_OK;

@@ -42,7 +42,9 @@ struct KernelTimer {
     KernelTimer(const char* name, hipStream_t stream) : rec(g_timing_on ? timing_begin(name, stream) : nullptr), s(stream) {}
     ~KernelTimer() { if (rec) timing_end(rec, s); }
 };
-#define FDGS_TIMED(name, stream) fdgs::KernelTimer fdgs_kt_##__LINE__(name, stream)
+#define FDGS_CAT2(a, b) a##b
+#define FDGS_CAT(a, b) FDGS_CAT2(a, b)
+#define FDGS_TIMED(name, stream) fdgs::KernelTimer FDGS_CAT(fdgs_kt_, __LINE__)(name, stream)
 
 constexpr int TILE = FDGS_TILE;
 constexpr int TILE_PIX = TILE * TILE;  // 256 threads = 4 wave64 per tile

@@ -176,7 +176,11 @@ def deform(net, xyz, scales, rotations, opacity, shs=None, shs_dc=None, shs_rest
     planes, mlp = _collect(net)
     dn = net.deformation_net
     cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
-               head_on=_head_on(dn.args), activate=bool(activate))
+               head_on=_head_on(dn.args), activate=bool(activate),
+               # grad mode is read HERE: inside autograd.Function.forward it is always off, and needs_input_grad stays True
+               # under torch.no_grad() -- evaluation frames (render.py, training_report) must not allocate ~3.2 KB per
+               # Gaussian of saved activations nor take the slower saving forward
+               save=bool(SAVE_ACTIVATIONS and torch.is_grad_enabled()))
     if isinstance(time, torch.Tensor):
         t_tensor, t_scalar = time, 0.0
     else:
@@ -266,7 +270,7 @@ class _DeformFunction(torch.autograd.Function):
         o_norm = torch.empty(N, device=dev) if cfg["activate"] else None
         out.xyz, out.scales, out.rotations, out.opacity, out.shs, out.rot_norm = ptr(o_xyz), ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_sh), ptr(o_norm)
         saved = None
-        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):
+        if cfg["save"] and any(ctx.needs_input_grad):
             nbytes = _lib.c_size_t()
             check(L.fdgs_deform_saved_bytes(p, nbytes))
             saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
@@ -283,6 +287,7 @@ class _DeformFunction(torch.autograd.Function):
                           sh_b=None if sh_b is None else sh_b.shape)
         ctx.plane_shapes = [tuple(q.shape) for q in planes_in]
         ctx.needs = ctx.needs_input_grad
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL pointers, which the kernels skip
         return o_xyz, o_sc, o_rot, o_op, o_sh
 
     @staticmethod

@@ -97,6 +97,12 @@ def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.
     n_out = kept + clones + 2 * splits
     if splits and normals is None:
         normals = torch.randn(2 * splits, 3, device=dev)
+        # data-parallel replicas must split identically: the plan (kept / clones / splits) is a function of statistics the
+        # caller has already reduced over ranks (parallel.allreduce_densification_stats), but the children's positions are
+        # sampled -- rank 0's samples are used everywhere instead of relying on lock-stepped per-rank RNG streams
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(normals, src=0)
     if normals is not None:
         normals = _f32(normals)
         if normals.shape[0] < 2 * splits:

@@ -36,11 +36,14 @@ def _pair(a, b):
 
 class _L1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, grad_on):
         x, y = _pair(a, b)
         n = x.numel()
         acc = torch.zeros(3, device=x.device, dtype=torch.float32)
-        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        # grad_on = torch.is_grad_enabled() at the call site: needs_input_grad stays True under torch.no_grad(), and
+        # evaluation (training_report, render.py) must not pay for a gradient image that no backward will read
+        grad = torch.empty_like(x) if (grad_on and ctx.needs_input_grad[0]) else None
+        ctx.saved_grad_image = grad is not None
         check(_lib.lib().fdgs_l1_stats(stream_ptr(), n, ptr(x), ptr(y), 1.0 / max(n, 1), ptr(grad), ptr(acc)))
         if grad is not None:
             ctx.save_for_backward(grad)
@@ -49,12 +52,12 @@ class _L1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return g * grad, None
+        return g * grad, None, None
 
 
 def l1_loss(network_output, gt):
     """mean |network_output - gt| (utils/loss_utils.py:20-21)."""
-    return _L1.apply(network_output, gt)
+    return _L1.apply(network_output, gt, torch.is_grad_enabled())
 
 
 def l2_loss(network_output, gt):
@@ -105,9 +108,10 @@ def _bwd(x, y, maps, w_l1, w_ssim, gs):
 
 class _SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, size_average):
+    def forward(ctx, a, b, size_average, grad_on):
         x, y = _pair(_as4(a), _as4(b))
-        need = ctx.needs_input_grad[0]
+        need = bool(grad_on and ctx.needs_input_grad[0])
+        ctx.saved_maps = need
         acc, maps = _fwd(x, y, need)
         ctx.size_average, ctx.shape = size_average, a.shape
         if need:
@@ -124,7 +128,7 @@ class _SSIM(torch.autograd.Function):
             d = _bwd(x, y, maps, 0.0, 1.0 / (n_item * x.shape[0]), gs)
         else:
             d = _bwd(x, y, maps, 0.0, 1.0 / n_item, None) * g.detach().float().view(-1, 1, 1, 1)
-        return d.view(ctx.shape), None, None
+        return d.view(ctx.shape), None, None, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
@@ -132,7 +136,7 @@ def ssim(img1, img2, window_size=11, size_average=True):
     batch item when size_average is False."""
     if window_size != 11:
         raise NotImplementedError("the kernel implements the reference's fixed window_size = 11")
-    return _SSIM.apply(img1, img2, bool(size_average))
+    return _SSIM.apply(img1, img2, bool(size_average), torch.is_grad_enabled())
 
 
 ImageLoss = namedtuple("ImageLoss", ["loss", "l1", "mse", "ssim"])
@@ -140,10 +144,11 @@ ImageLoss = namedtuple("ImageLoss", ["loss", "l1", "mse", "ssim"])
 
 class _ImageLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, lam):
+    def forward(ctx, a, b, lam, grad_on):
         x, y = _pair(_as4(a), _as4(b))
         n = max(x.numel(), 1)
-        need = ctx.needs_input_grad[0]
+        need = bool(grad_on and ctx.needs_input_grad[0])
+        ctx.saved_maps = need
         ctx.shape = a.shape
         if lam == 0.0:
             acc = torch.zeros(3, device=x.device, dtype=torch.float32)
@@ -169,15 +174,15 @@ class _ImageLoss(torch.autograd.Function):
     def backward(ctx, g, *_unused):
         if not ctx.fused:
             (grad,) = ctx.saved_tensors
-            return (g * grad).view(ctx.shape), None, None
+            return (g * grad).view(ctx.shape), None, None, None
         x, y, maps = ctx.saved_tensors
         n = max(x.numel(), 1)
         gs = g.detach().float().reshape(1).contiguous()
-        return _bwd(x, y, maps, 1.0 / n, -ctx.lam / n, gs).view(ctx.shape), None, None
+        return _bwd(x, y, maps, 1.0 / n, -ctx.lam / n, gs).view(ctx.shape), None, None, None
 
 
 def image_loss(image, gt, lambda_dssim=0.0):
     """Fused `Ll1 + lambda_dssim * (1 - ssim(image, gt))` of train.py:201-214.  Returns ImageLoss(loss, l1, mse, ssim):
     `loss` carries the gradient to `image`; l1 / mse / ssim are detached 0-dim device tensors (psnr = -10 log10(mse);
     ssim is NaN when lambda_dssim == 0 and the SSIM pass is skipped, as the reference skips it)."""
-    return ImageLoss(*_ImageLoss.apply(image, gt, float(lambda_dssim)))
+    return ImageLoss(*_ImageLoss.apply(image, gt, float(lambda_dssim), torch.is_grad_enabled()))

@@ -18,15 +18,76 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_cuda = torch.cuda.is_available()
+    use_cuda = torch.cuda.is_available() and backend != "gloo"
     device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
     if use_cuda:
+        n_vis = torch.cuda.device_count()
+        if local >= n_vis:
+            raise RuntimeError(f"rank {rank} (LOCAL_RANK {local}) has no GPU of its own: {n_vis} device(s) visible; "
+                               "the frame-parallel path runs one process per GPU and never shares a device")
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
     return rank, world, device
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn_entry(rank, world, port, fn, args):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+    try:
+        fn(*args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def spawn_local(world, fn, args=()):
+    """Launcher-free form of `torch.distributed.run --nnodes=1 --nproc-per-node world`: starts `world` processes on this
+    node, rank r with RANK = LOCAL_RANK = r (-> cuda:r in init_from_env), rendezvous on 127.0.0.1 at a free port, and
+    calls fn(*args) in each.  Raises if any rank exits non-zero.  `fn` must be importable (module-level)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_spawn_entry, args=(r, world, port, fn, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bad = []
+    for r, p in enumerate(procs):
+        p.join()
+        if p.exitcode != 0:
+            bad.append((r, p.exitcode))
+    if bad:
+        raise RuntimeError(f"spawn_local: ranks exited non-zero: {bad}")
+
+
+def ranks_seen(device):
+    """Number of ranks that took part in one all-reduce(SUM) of ones: proof that every rank joined the RCCL job."""
+    t = torch.ones(1, device=device, dtype=torch.float32)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def gather_floats(value, device):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+    return [float(value)]
 
 
 def frames_for_rank(n_frames_total, step, rank, world):
@@ -70,17 +131,27 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False):
     gradient of a step is the SUM over its views: with the views spread over ranks that is one all-reduce(sum).  Gradients
     are packed into few large flat buckets first (one for the whole model at 300 k Gaussians: ~71 MB of Gaussian rows +
     <= 30 MB of planes and MLP weights): xGMI is point-to-point, a ring all-reduce is bound per link, and a handful of
-    100-MB messages use the links far better than hundreds of small tensors would.  Parameters whose grad is None on
-    every rank are skipped; a grad that is None on this rank only is treated as zeros (heads the config switches off get
-    no gradient anywhere, so this cannot deadlock as long as all ranks run the same configuration).
-    Returns the number of collectives issued."""
+    100-MB messages use the links far better than hundreds of small tensors would.  The parameter LIST (same order on
+    every rank) is authoritative: one small all-reduce(MAX) of a has-grad mask runs first; a parameter whose grad is None
+    on every rank is skipped everywhere, one whose grad is None on this rank only gets `zeros_like(p)` here, so the flat
+    buckets have the same size on all ranks whatever each rank's views happened to touch.
+    Returns the number of gradient collectives issued (the mask exchange is not counted)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return 0
     world = dist.get_world_size()
+    params = list(params)
+    if not params:
+        return 0
+    dev0 = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+    has = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev0)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX)
+    has = has.tolist()
     groups = {}
-    for p in params:
-        if p.grad is None:
+    for p, h in zip(params, has):
+        if not h:
             continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
         groups.setdefault((p.grad.dtype, p.grad.device), []).append(p.grad)
     calls = 0
     for (_, _), grads in sorted(groups.items(), key=lambda kv: str(kv[0])):

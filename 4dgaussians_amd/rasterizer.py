@@ -151,10 +151,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                    scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
         ctx.shapes = (opacities.shape, None if sh is None else sh.shape)
         ctx.mark_non_differentiable(radii)
+        # an output the loss never used must arrive in backward as None, not as a materialised zero image: the
+        # reference's training loss ignores `depth` (train.py:201-214), and a NULL dL_ddepth selects the blending
+        # backward without the depth terms (render_bwd_kernel<false>, csrc/render.hip)
+        ctx.set_materialize_grads(False)
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth):
+        if grad_color is None:
+            if grad_depth is None:      # neither image reached the loss
+                return (None,) * 9
+            grad_color = torch.zeros(3, ctx.state.params.H, ctx.state.params.W, device=grad_depth.device)
         g = rasterize_backward(ctx.state, grad_color, grad_depth)
         had_sh, had_col, had_scale, had_cov = ctx.had
         op_shape, sh_shape = ctx.shapes

@@ -7,7 +7,10 @@ fixed random target, at BASELINE config 4 shape (DyNeRF cook_spinach: 300k Gauss
 config, all five heads).  N GPUs = N independent frames per step (weak scaling) + one RCCL all-reduce of the loss
 statistics.  Synthetic scene: no datasets/checkpoints exist offline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when
+WORLD_SIZE is unset, bench.py spawns its N ranks itself (parallel.spawn_local: one process per GPU, rank r -> cuda:r, RCCL
+rendezvous on 127.0.0.1) and fails with a clear message when fewer than N GPUs are visible.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -61,14 +64,37 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary full-iteration measurement")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: spawn the ranks ourselves (one process per GPU); every child re-enters run() with the torchrun
+        # environment contract, rank 0 prints the JSON line
+        par = importlib.import_module("4dgaussians_amd.parallel")
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node "
+                             "(one rank per GPU; there is no CPU fallback and ranks never share a device)")
+        par.spawn_local(args.gpus, _spawned, (vars(args),))
+        return
+    run(args)
+
+
+def _spawned(argdict):
+    run(argparse.Namespace(**argdict))
+
+
+def run(args):
     fdgs = importlib.import_module("4dgaussians_amd")
     par, syn = fdgs.parallel, fdgs.synthetic
     rank, world, dev = par.init_from_env()
     if dev.type != "cuda":
         raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ranks_seen = par.ranks_seen(dev)          # all-reduce of ones over RCCL: every rank really joined the job
+    if ranks_seen != world:
+        raise SystemExit(f"RCCL saw {ranks_seen} ranks, expected {world}")
     L = fdgs._lib.lib()
     N, W, H, dcfg = WORKLOADS[args.workload]
     pc = syn.SynthModel(N, dcfg, seed=6666, device=dev)
@@ -98,12 +124,20 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    par.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    par.barrier(); torch.cuda.synchronize()
-    dt = par.max_over_ranks(time.perf_counter() - t0, dev)
+    # `repeats` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over ranks; value = median region (a single 20-step region is 80 ms -- too thin a sample to be robust
+    # against one clock ramp or one stray host interrupt); all regions are listed in the JSON line
+    regions, local_regions = [], []
+    for r_ in range(max(args.repeats, 1)):
+        par.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + r_ * args.steps + i)
+        par.barrier(); torch.cuda.synchronize()
+        local_regions.append(time.perf_counter() - t0)
+        regions.append(par.max_over_ranks(local_regions[-1], dev))
+    dt = sorted(regions)[len(regions) // 2]
+    per_rank_ms = [x / args.steps * 1e3 for x in par.gather_floats(sorted(local_regions)[len(local_regions) // 2], dev)]
     l1, psnr = par.loss_from_stats(acc.clone())
     fps = world * args.steps / dt
 
@@ -167,7 +201,7 @@ def main():
                         traffic=None, avg_launch_ms=kern[dom]["avg_ms"], launches_per_step=lps)
 
     if roof is not None:
-        roof.update(pmc_traffic(dom))
+        roof.update(pmc_traffic(dom, args.workload, lib_sha16(fdgs)))
 
     # ---- secondary measurement: one full fine-stage iteration of train.py (180-292) without data loading / densification:
     # render fwd+bwd + L1 statistics + HexPlane regulariser fwd+bwd (train.py:208-211) + optimizer step (:291-292), the
@@ -208,18 +242,22 @@ def main():
         train = {"iterations_per_s": world * args.steps / dt_tr, "ms_per_iteration": dt_tr / args.steps * 1e3,
                  "includes": "render fwd+bwd, L1 stats, densification statistics, HexPlane regulariser fwd+bwd, FusedAdam step over all 8 parameter groups (lr = 0)",
                  "extra_kernels_ms_per_iteration": extra}
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(fdgs, syn, pc, cams[args.warmup % len(cams)], target, dcfg, args.cpu_frames)
+        cam_p = cams[args.warmup % len(cams)]
+        cpu, ref = cpu_baseline(fdgs, syn, pc, cam_p, target, dcfg, args.cpu_frames)
+        parity = parity_vs_oracle(fdgs, pc, cam_p, pipe, bg, params, ref)
 
     if rank == 0:
         out = {
             "metric": "train-step frames/sec (fwd+bwd raster+deform)", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "lib_sha16": lib_sha16(fdgs),
             "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
-            "roofline": roof, "cpu_baseline": cpu, "train_iteration": train,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "train_iteration": train,
+            "ranks_seen": ranks_seen, "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+            "timed_regions_ms_per_step": [round(x / args.steps * 1e3, 4) for x in regions], "value_is": "median of the timed regions",
             "frame_hbm": {"algorithmic_bytes": B_frame, "achieved_GBps": B_frame / (dt / args.steps / 1) / 1e9 if world == 1 else None,
                           "frac_of_8TBps": (B_frame / (dt / args.steps)) / HBM_PEAK if world == 1 else None,
                           "note": "working set < 256 MiB Infinity Cache at this size: the HBM fraction is structurally small"},
@@ -233,24 +271,40 @@ def main():
         print(json.dumps(out))
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same bench command).  Corrections per
-    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; on gfx950 FETCH_SIZE reports half the bytes
-    of 16-B-per-lane streaming reads, which is what the MLP / per-Gaussian kernels issue, so it is doubled.  WRITE_SIZE is
-    uncalibrated there and taken as reported.  null when no PMC artefact is present."""
+def lib_sha16(fdgs):
+    import hashlib
+    return hashlib.sha256(open(fdgs._lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel, workload, lib_sha):
+    """HBM-side bytes per launch of `kernel` from a committed rocprofv3 PMC artefact (profiles/*_pmc_traffic*.json, written by
+    tools/pmc_traffic.py from separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same bench command).  An
+    artefact is only used when it was collected for THIS workload with THIS build of libfdgs.so (`_workload`, `_lib_sha16`
+    keys): anything else gives traffic = null plus the reason -- a counter from another workload or build is not a
+    measurement of this run.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; on
+    gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads (what these kernels issue), so it is
+    doubled; WRITE_SIZE is uncalibrated there and taken as reported."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return {"traffic": None}
-    d = json.load(open(files[-1]))
-    k = d.get(kernel)
-    if not k:
-        return {"traffic": None, "traffic_source": os.path.basename(files[-1]) + " (kernel not profiled)"}
-    fetch, write = k.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024, k.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
-    return {"traffic": 2 * fetch + write, "traffic_unit": "bytes/launch",
-            "traffic_detail": {"FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_bytes_corrected_x2": 2 * fetch, "WRITE_SIZE_bytes": write},
-            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))
+    reasons = []
+    for f in reversed(files):
+        d = json.load(open(f))
+        if d.get("_workload") != workload:
+            reasons.append(f"{os.path.basename(f)}: workload {d.get('_workload')!r}")
+            continue
+        if d.get("_lib_sha16") != lib_sha:
+            reasons.append(f"{os.path.basename(f)}: other build ({d.get('_lib_sha16')})")
+            continue
+        k = d.get(kernel)
+        if not k:
+            return {"traffic": None, "traffic_source": os.path.basename(f) + " (kernel not profiled)"}
+        fetch, write = k.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024, k.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
+        return {"traffic": 2 * fetch + write, "traffic_unit": "bytes/launch",
+                "traffic_detail": {"FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_bytes_corrected_x2": 2 * fetch, "WRITE_SIZE_bytes": write},
+                "traffic_source": "profiles/" + os.path.basename(f)}
+    return {"traffic": None, "traffic_source": None,
+            "traffic_refused": ("no PMC artefact for this workload and build (libfdgs sha16 " + lib_sha + "); not used: " + "; ".join(reasons[:4]))
+            if reasons else "no PMC artefact under profiles/"}
 
 
 def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
@@ -274,8 +328,9 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
     tgt = target.cpu().numpy()
     n = leaves["_xyz"].shape[0]
     stage = {"deform_fwd": 0.0, "raster_fwd": 0.0, "raster_bwd": 0.0, "deform_bwd": 0.0}
+    ref = None
     t0 = time.perf_counter()
-    for _ in range(frames):
+    for fi in range(frames):
         ta = time.perf_counter()
         shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
         outs = DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
@@ -292,17 +347,64 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
         td = time.perf_counter()
         gouts = [torch.tensor(g["means3D"]), torch.tensor(g["scales"]), torch.tensor(g["rotations"]),
                  torch.tensor(g["opacities"]).reshape(outs[3].shape), torch.tensor(g["shs"]).reshape(outs[4].shape)]
-        torch.autograd.grad(list(outs), list(leaves.values()) + [v for v in sd.values() if v.requires_grad], grad_outputs=gouts,
-                            allow_unused=True)
+        wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
+        gref = torch.autograd.grad(list(outs), wanted, grad_outputs=gouts, allow_unused=True)
         te = time.perf_counter()
+        if fi == 0:   # the oracle's image, depth and every gradient of this frame: the checker of parity_vs_oracle()
+            names = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
+            ref = dict(color=o.color.copy(), depth=o.depth.copy(), dc=dc, means2D=g["means2D"].copy(), radii=o.radii.copy(),
+                       grads={k: (None if v is None else v.numpy()) for k, v in zip(names, gref)})
         o.close()
         for k_, v_ in zip(stage, (tb - ta, tc - tb, td - tc, te - td)):
             stage[k_] += v_
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+    return ({"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s wall on {threads} threads of {cores} host cores; "
                       "deformation = oracle pinned to the reference modules (torch CPU), rasterizer = our C restatement (OpenMP)",
-            "stage_seconds": {k_: round(v_, 3) for k_, v_ in stage.items()}}
+            "stage_seconds": {k_: round(v_, 3) for k_, v_ in stage.items()}}, ref)
+
+
+def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
+    """The headline checks itself: the frame the CPU leg just computed with the oracle chain (deformation oracle pinned to
+    the reference's modules -> C rasterizer restatement, forward + analytic backward -> torch-CPU autograd) is rendered
+    through the HIP path with the SAME upstream image gradient, and image, depth, radii and every parameter gradient are
+    compared.  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+        d = np.linalg.norm(b)
+        return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a))
+
+    for p_ in params:
+        p_.grad = None
+    res = fdgs.render(cam, pc, pipe, bg, stage="fine")
+    img = res["render"]
+    img.backward(torch.tensor(ref["dc"], device=img.device))
+    torch.cuda.synchronize()
+    im, dp = img.detach().cpu().numpy(), res["depth"].detach().cpu().numpy()
+    mse = float(((im.astype(np.float64) - ref["color"]) ** 2).mean())
+    named = dict(pc.named_parameters())
+    groups = {"xyz": ["_xyz"], "scaling": ["_scaling"], "rotation": ["_rotation"], "opacity": ["_opacity"], "f_dc": ["_features_dc"],
+              "f_rest": ["_features_rest"],
+              "planes": [k for k in ref["grads"] if "grids" in k and ref["grads"][k] is not None],
+              "mlp": [k for k in ref["grads"] if k.startswith("_deformation.") and "grids" not in k and ref["grads"][k] is not None]}
+    grad_rel = {}
+    for gname, keys in groups.items():
+        a = np.concatenate([named[k].grad.detach().cpu().numpy().ravel() for k in keys])
+        b = np.concatenate([ref["grads"][k].ravel() for k in keys])
+        grad_rel[gname] = rel(a, b)
+    worst_tensor = max(((k, rel(named[k].grad.detach().cpu().numpy(), v)) for k, v in ref["grads"].items()
+                        if v is not None and float(np.abs(v).max()) > 0), key=lambda kv: kv[1])
+    radii = res["radii"].cpu().numpy()
+    return {"frame": "the cpu_baseline frame (same camera, same upstream image gradient)",
+            "image_psnr_dB": 10 * math.log10(1.0 / max(mse, 1e-20)), "image_mean_abs": float(np.abs(im - ref["color"]).mean()),
+            "image_max_abs": float(np.abs(im - ref["color"]).max()), "depth_mean_abs": float(np.abs(dp - ref["depth"]).mean()),
+            "radii_mismatch_frac": float((radii != ref["radii"]).mean()),
+            "grad_rel_l2": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},
+            "viewspace_rel_l2": float(f"{rel(res['viewspace_points'].grad.cpu().numpy(), ref['means2D']):.3e}"),
+            "worst_single_tensor": {"name": worst_tensor[0], "rel_l2": float(f"{worst_tensor[1]:.3e}")},
+            "tolerance": {"image_psnr_dB": ">= 80", "grad_rel_l2": "<= 1e-3 (north_star)"}}
 
 
 if __name__ == "__main__":

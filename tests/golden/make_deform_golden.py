@@ -35,9 +35,21 @@ def main():
         shs = torch.cat([g["features_dc"], g["features_rest"]], 1)
         t = torch.rand(n, 1)
         t[:4] = torch.tensor([[0.0], [1.0], [0.5], [1.2]])
-        with torch.no_grad():
-            out = net(xyz, g["scaling"], g["rotation"], g["opacity"], shs, t)
+        # forward + backward of the REFERENCE modules: outputs, and the gradients of sum(out * w) for seeded weights w
+        # with respect to every input and every parameter (the GPU tests compare the HIP backward with these directly)
+        ins = [x.clone().requires_grad_(True) for x in (xyz, g["scaling"], g["rotation"], g["opacity"], shs)]
+        out = net(*ins, t)
+        ws = [torch.randn(o.shape, generator=torch.Generator().manual_seed(99 + i)) for i, o in enumerate(out)]
+        pnames = [k for k, p in net.named_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(sum((o * w).sum() for o, w in zip(out, ws)), ins + [dict(net.named_parameters())[k] for k in pnames],
+                                    allow_unused=True)
+        out = [o.detach() for o in out]
         d = {"sd." + k: v.detach().numpy() for k, v in net.state_dict().items()}
+        for k, w in zip(("xyz", "scales", "rot", "opacity", "shs"), ws):
+            d["w." + k] = w.numpy()
+        for k, gr in zip(["in.xyz", "in.scales", "in.rot", "in.opacity", "in.shs"] + ["sd." + k for k in pnames], grads):
+            if gr is not None:
+                d["grad." + k] = gr.numpy()
         for k, v in zip(("xyz", "scales", "rot", "opacity", "shs", "t"), (xyz, g["scaling"], g["rotation"], g["opacity"], shs, t)):
             d["in." + k] = v.numpy()
         for k, v in zip(("xyz", "scales", "rot", "opacity", "shs"), out):

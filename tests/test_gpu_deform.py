@@ -120,16 +120,14 @@ def _parity(cfg, n, activate, scalar_time=None):
         assert v < 1e-4, (k, v)
 
 
-@pytest.mark.parametrize("cfg,n", [("dynerf_default", 3000)])
-def test_deform_unfiltered_inputs_loose(cfg, n):
-    """Unfiltered random inputs: a handful of the ~2M ReLU inputs lie within float rounding of 0 and flip between the
-    GPU's fmaf chain and the CPU's sgemm; each flip perturbs a single row of a weight gradient.  The comparison is
-    therefore loose here (and tight on inputs away from the kinks above)."""
+def _grads_pair(cfg, n, seed, upstream_mask=None):
+    """HIP and oracle gradients of sum(out * w) on UNFILTERED random inputs; `upstream_mask` [n] zeroes w for some rows."""
     dev = torch.device("cuda:0")
     fd = _fdgs()
-    args, net, ins = _net_and_inputs(cfg, n, 9, dev, safe=False)
+    args, net, ins = _net_and_inputs(cfg, n, seed, dev, safe=False)
     sd = {k: v.detach().clone().contiguous().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
           for k, v in net.state_dict().items()}
+    margin = DO.discontinuity_margin(net.state_dict(), args, ins[0], ins[5])
     cpu_in = [x.clone().requires_grad_(i < 5) for i, x in enumerate(ins)]
     ref = DO.deform_forward(sd, args, *cpu_in, activate=True)
     net = net.to(dev)
@@ -138,13 +136,138 @@ def test_deform_unfiltered_inputs_loose(cfg, n):
     for a, b in zip(out, ref):
         assert rel_l2(a.detach().cpu().numpy(), b.detach().numpy().reshape(a.shape)) < 2e-5
     ws = [torch.randn(b.shape, generator=torch.Generator().manual_seed(1)) for b in ref]
+    if upstream_mask is not None:
+        ws = [w * upstream_mask.reshape([-1] + [1] * (w.dim() - 1)).to(w.dtype) for w in ws]
     pn = [k for k in sd if sd[k].requires_grad]
     g_ref = torch.autograd.grad(sum((a * w).sum() for a, w in zip(ref, ws)), cpu_in[:5] + [sd[k] for k in pn], allow_unused=True)
     g_gpu = torch.autograd.grad(sum((a * w.to(dev).reshape(a.shape)).sum() for a, w in zip(out, ws)),
                                 gpu_in[:5] + [dict(net.named_parameters())[k] for k in pn], allow_unused=True)
-    for a, b in zip(g_gpu, g_ref):
+    names = ["xyz", "scales", "rot", "opacity", "shs"] + pn
+    return names, g_gpu, g_ref, margin
+
+
+@pytest.mark.parametrize("cfg,n", [("dynerf_default", 3000), ("dynerf_default", 60000), ("hypernerf_default", 20000)])
+def test_deform_unfiltered_inputs_flips_counted(cfg, n):
+    """Unfiltered random inputs, north_star tolerance (1e-3), no pre-filtering of the comparison set.
+
+    The deformation's derivative is discontinuous where a ReLU input crosses 0 or a HexPlane coordinate crosses a texel
+    boundary.  A Gaussian sitting within float rounding of such a kink can fall on different sides in the GPU's fmaf chain
+    and the CPU's sgemm: its forward value is unaffected (the function is continuous) but its gradient contribution flips.
+    This test QUANTIFIES that instead of loosening the tolerance:
+      1. at-risk rows = Gaussians whose oracle margin to the nearest kink is < 4e-6; their number must stay below a stated
+         bound (they are a property of the inputs, not of the kernel);
+      2. with the full upstream gradient, the per-Gaussian input gradients of HIP and oracle may only disagree (> 1e-3 of the
+         row scale) on at-risk rows -- every flip is explained -- and the count of such rows is bounded;
+      3. with the upstream gradient of the at-risk rows set to zero (their contribution vanishes on both sides whichever way
+         they flip) EVERY gradient, including all weight and plane gradients, agrees to 1e-3 rel-L2."""
+    names, g_gpu, g_ref, margin = _grads_pair(cfg, n, 9)
+    risky = (margin < 4e-6).numpy()
+    n_relu = n * (1 + 5) * 128
+    bound = max(8, int(4e-5 * n_relu))           # density of pre-activations near 0 is O(1): expect ~ 1e-5 * n_relu
+    assert risky.sum() <= bound, f"{risky.sum()} at-risk rows of {n}"
+    flipped = np.zeros(n, bool)
+    for k, a, b in zip(names[:5], g_gpu[:5], g_ref[:5]):
+        A, B = a.cpu().numpy().reshape(n, -1), b.numpy().reshape(n, -1)
+        scale = np.linalg.norm(B) / math.sqrt(n) + 1e-30
+        flipped |= np.linalg.norm(A - B, axis=1) / scale > 1e-3
+    print(f"[{cfg} n={n}] at-risk rows {int(risky.sum())}, rows whose input gradient differs {int(flipped.sum())} (bound {bound})")
+    assert not np.any(flipped & ~risky), f"{int((flipped & ~risky).sum())} rows differ without being near a kink"
+    assert flipped.sum() <= bound
+    names, g_gpu, g_ref, _ = _grads_pair(cfg, n, 9, upstream_mask=torch.tensor(~risky))
+    worst = {}
+    for k, a, b in zip(names, g_gpu, g_ref):
         if b is not None:
-            assert rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape)) < 2e-2
+            worst[k] = rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print("   masked-upstream worst rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in top))
+    for k, v in worst.items():
+        assert v < 1e-3, (k, v)
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("cfg", ["dnerf_bouncingballs", "hypernerf_default", "dynerf_default"])
+def test_deform_matches_reference_golden_vectors(cfg):
+    """The HIP deformation against the fixtures generated by the REFERENCE's own modules (tests/golden/make_deform_golden.py):
+    the reference state_dict loads strictly into this package's deform_network, forward outputs and the gradients of
+    sum(out * w) w.r.t. every input and every parameter are compared with the stored reference results directly."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    z = np.load(__import__("os").path.join(GOLD, f"deform_{cfg}.npz"))
+    args = synthetic.deform_args(cfg)
+    args.kplanes_config["resolution"] = [8, 8, 8, 6]          # the fixtures' (small) plane resolution
+    net = fd.deform_network(args)
+    missing = net.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net = net.to(dev)
+    keys = ("xyz", "scales", "rot", "opacity", "shs")
+    ins = [torch.tensor(z["in." + k], device=dev).requires_grad_(True) for k in keys]
+    t = torch.tensor(z["in.t"], device=dev)
+    out = net(*ins, t)
+    for k, o in zip(keys, out):
+        assert rel_l2(o.detach().cpu().numpy(), z["out." + k]) < 2e-5, k
+    loss = sum((o * torch.tensor(z["w." + k], device=dev)).sum() for k, o in zip(keys, out))
+    gk = [k for k in z.files if k.startswith("grad.")]
+    named = dict(net.named_parameters())
+    wanted = [ins[keys.index(k[8:])] if k.startswith("grad.in.") else named[k[8:]] for k in gk]
+    grads = torch.autograd.grad(loss, wanted, allow_unused=True)
+    worst = {}
+    for k, g in zip(gk, grads):
+        assert g is not None, k
+        worst[k] = rel_l2(g.cpu().numpy(), z[k])
+    print(f"[golden {cfg}] worst: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:3]))
+    for k, v in worst.items():
+        assert v < 1e-3, (k, v)       # 96 unfiltered Gaussians: north_star tolerance
+
+
+def test_backward_with_unused_outputs_and_no_grad_forward():
+    """(a) Only some outputs reach the loss: autograd hands None for the others (set_materialize_grads(False)) and the
+    kernels skip them -- gradients must equal the oracle's for the same partial loss.  (b) Under torch.no_grad() the forward
+    neither allocates the saved-activation buffer nor takes the saving path."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs("dynerf_default", 700, 4, dev)
+    sd = {k: v.detach().clone().contiguous().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in net.state_dict().items()}
+    cpu_in = [x.clone().requires_grad_(i < 5) for i, x in enumerate(ins)]
+    ref = DO.deform_forward(sd, args, *cpu_in, activate=True)
+    net = net.to(dev)
+    gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
+    out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=True)
+    gen = torch.Generator().manual_seed(5)
+    w0, w3 = torch.randn(ref[0].shape, generator=gen), torch.randn(ref[3].shape, generator=gen)
+    pn = [k for k in sd if sd[k].requires_grad]
+    g_ref = torch.autograd.grad((ref[0] * w0).sum() + (ref[3] * w3).sum(), cpu_in[:5] + [sd[k] for k in pn], allow_unused=True)
+    g_gpu = torch.autograd.grad((out[0] * w0.to(dev)).sum() + (out[3] * w3.to(dev)).sum(),
+                                gpu_in[:5] + [dict(net.named_parameters())[k] for k in pn], allow_unused=True)
+    for k, a, b in zip(["xyz", "scales", "rot", "opacity", "shs"] + pn, g_gpu, g_ref):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) == 0.0, k
+        else:
+            assert rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape)) < 1e-4, k
+    with torch.no_grad():
+        o2 = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=True)
+    assert o2[0].grad_fn is None
+    # the Function object is not reachable without a graph: check through the module-level hook instead
+    seen = {}
+    orig = fd._lib.lib().fdgs_deform_saved_bytes
+
+    class Spy:
+        def __call__(self, *a):
+            seen["called"] = True
+            return orig(*a)
+    fd._lib.lib().fdgs_deform_saved_bytes = Spy()
+    try:
+        with torch.no_grad():
+            fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=True)
+        assert "called" not in seen, "saved-activation buffer sized/allocated under no_grad"
+        fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=gpu_in[5], activate=True)
+        assert seen.get("called"), "grad mode on: the saving forward is expected"
+    finally:
+        fd._lib.lib().fdgs_deform_saved_bytes = orig
+    for a, b in zip(o2, out):
+        assert torch.equal(a, b.detach())
 
 
 def test_aabb_host_copy_is_keyed_on_the_tensor_object_not_its_address():

@@ -1,0 +1,84 @@
+"""Parity at the sizes the headline is quoted on (BASELINE.json configs 2, 3, 4): render() forward + backward through the HIP
+path against the oracle chain on the SAME frame -- image, depth, radii, every Gaussian-parameter gradient, every HexPlane and
+MLP gradient, the view-space gradient.  The small-size tests exercise one tile round per CU; these run the persistent tile
+loops (9 rounds per CU), the cost-model work split of the weight-gradient kernel, the LDS-privatised time planes at full
+occupancy, the multi-chunk scans and the multi-million-pair sort -- with the numbers looked at.
+
+Tolerances (north_star): image PSNR vs oracle >= 80 dB, gradients <= 1e-3 rel-L2 per parameter group."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import oracle_render_chain, rel_l2
+
+pytestmark = pytest.mark.gpu
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+CONFIGS = {
+    "cfg2_dnerf_100k_800x800": (100_000, 800, 800, "dnerf_bouncingballs"),
+    "cfg3_hypernerf_300k_536x960": (300_000, 536, 960, "hypernerf_default"),
+    "cfg4_dynerf_300k_1352x1014": (300_000, 1352, 1014, "dynerf_default"),
+}
+
+
+def _groups(grads):
+    g = {"xyz": ["_xyz"], "scaling": ["_scaling"], "rotation": ["_rotation"], "opacity": ["_opacity"], "f_dc": ["_features_dc"],
+         "f_rest": ["_features_rest"],
+         "planes": [k for k in grads if "grids" in k and grads[k] is not None],
+         "mlp": [k for k in grads if k.startswith("_deformation.") and "grids" not in k and grads[k] is not None]}
+    return g
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("with_depth", [False])
+def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth):
+    fd = importlib.import_module("4dgaussians_amd")
+    dev = torch.device("cuda:0")
+    N, W, H, dcfg = CONFIGS[name]
+    pc = synthetic.SynthModel(N, dcfg, seed=6666)                  # the bench scene
+    cam = synthetic.orbit_cameras(W, H, n=160)[8]
+    o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth)
+    pc = pc.to(dev)
+    res = fd.render(cam.to(dev), pc, synthetic.PipelineParams(), torch.zeros(3, device=dev), stage="fine")
+    img = res["render"]
+    loss = (img * torch.tensor(dc, device=dev)).sum()
+    if with_depth:
+        loss = loss + (res["depth"] * torch.tensor(dd, device=dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    im = img.detach().cpu().numpy()
+    d = np.abs(im - o.color)
+    psnr = 10 * math.log10(1.0 / max(float(((im.astype(np.float64) - o.color) ** 2).mean()), 1e-20))
+    dmean = float(np.abs(res["depth"].detach().cpu().numpy() - o.depth).mean())
+    radii = res["radii"].cpu().numpy()
+    mism = float((radii != o.radii).mean())
+    print(f"[{name}] visible {(o.radii > 0).sum()}  image psnr {psnr:.1f} dB  max|dC| {d.max():.2e}  mean {d.mean():.2e}  depth mean abs {dmean:.2e}  radii mismatch {mism:.2e}")
+    assert psnr >= 80.0 and d.mean() < 2e-6
+    assert dmean < 2e-5 and mism < 2e-4
+    named = dict(pc.named_parameters())
+    rep = {}
+    for gname, keys in _groups(gref).items():
+        a = np.concatenate([named[k].grad.cpu().numpy().ravel() for k in keys])
+        b = np.concatenate([gref[k].ravel() for k in keys])
+        rep[gname] = rel_l2(a, b)
+    rep["viewspace"] = rel_l2(res["viewspace_points"].grad.cpu().numpy(), gref["__means2D"])
+    per_tensor = {k: rel_l2(named[k].grad.cpu().numpy(), v) for k, v in gref.items()
+                  if not k.startswith("__") and v is not None and float(np.abs(v).max()) > 0}
+    worst = sorted(per_tensor.items(), key=lambda kv: -kv[1])[:4]
+    print("   group rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in rep.items()))
+    print("   worst tensors: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    for k, v in rep.items():
+        assert v <= 1e-3, (k, v)
+    # parameters of disabled heads / the unused time net get no gradient on either side
+    for k, v in gref.items():
+        if not k.startswith("__") and (v is None or float(np.abs(v).max()) == 0.0):
+            a = named[k].grad
+            assert a is None or float(a.abs().max()) < 1e-12, k
+
+
+def test_render_parity_with_depth_gradient_at_config4():
+    """Same as above with a gradient on the depth output too (the DEPTH instantiation of the blending backward)."""
+    test_render_fwd_bwd_parity_at_baseline_size("cfg4_dynerf_300k_1352x1014", True)

@@ -122,3 +122,26 @@ def test_full_size_properties_and_errors():
         losses.l1_loss(img, gt)          # CPU tensors: there is no CPU path
     e = torch.zeros(0, 3, 8, 8, device="cuda")
     assert losses.mse(e, e).shape == (0, 1)
+
+
+def test_no_grad_evaluation_allocates_no_backward_buffers(monkeypatch):
+    """training_report / render.py evaluate under torch.no_grad(): needs_input_grad stays True there, so the Functions gate
+    their saved buffers (SSIM partial-derivative maps, the L1 gradient image) on the grad mode of the call site."""
+    import importlib
+    losses = importlib.import_module("4dgaussians_amd.losses")
+    dev = torch.device("cuda:0")
+    img = torch.rand(3, 70, 90, device=dev, requires_grad=True)
+    gt = torch.rand(3, 70, 90, device=dev)
+    seen = []
+    orig = losses._fwd
+    monkeypatch.setattr(losses, "_fwd", lambda x, y, want: (seen.append(want), orig(x, y, want))[1])
+    with torch.no_grad():
+        a = losses.ssim(img, gt)
+        b = losses.image_loss(img, gt, 0.2).loss
+        c = losses.l1_loss(img, gt)
+    assert seen == [False, False] and a.grad_fn is None and b.grad_fn is None and c.grad_fn is None
+    a2, b2 = losses.ssim(img, gt), losses.image_loss(img, gt, 0.2).loss
+    assert seen[2:] == [True, True]
+    assert torch.allclose(a, a2) and torch.allclose(b, b2)
+    (a2 + b2 + losses.l1_loss(img, gt)).backward()
+    assert img.grad is not None and torch.isfinite(img.grad).all()

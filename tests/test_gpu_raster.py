@@ -83,6 +83,8 @@ CASES = [
     dict(n=3000, width=201, height=77, seed=1, theta=-100.0, scale_boost=4.0),   # ragged image edge, big splats
     dict(n=500, width=64, height=48, seed=2, theta=170.0, sh_degree=1, scale_boost=10.0),
     dict(n=5000, width=320, height=240, seed=3, theta=0.0, sh_degree=0, extent=3.0),  # many culled / behind camera
+    dict(n=300000, width=1352, height=1014, seed=6666, theta=-60.0),             # BASELINE config 4 shape, VALUES compared
+    dict(n=100000, width=800, height=800, seed=11, theta=100.0, scale_boost=2.0),  # BASELINE config 2 shape
 ]
 
 

@@ -1,0 +1,185 @@
+"""Every branch of the reference's render() (gaussian_renderer/__init__.py:18-138) executed through the HIP path.
+
+The reference holds two formulations of two pieces of rasterizer arithmetic in-tree: the python SH evaluation
+(`pipe.convert_SHs_python`, :106-111) and the python 3-D covariance (`pipe.compute_cov3D_python`, :74).  Rendering with the
+python formulation (colours / covariances precomputed with torch ops, handed to the rasterizer as *_precomp) must equal the
+native path (SH / covariance evaluated inside the HIP preprocess kernel) -- image to 1e-6, gradients to 1e-4: this ties the
+kernel's arithmetic to the reference's own python, the only rasterizer maths the reference has in-tree.
+Also: override_color (:113), cam_type == "PanopticSports" (:53-55), a foreign deformation module (non-fused fine stage),
+and the HIP preprocess kernel's cov3D / RGB against tests/golden/raster_pins.npz (reference python, see its generator)."""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from scenes import rel_l2
+
+pytestmark = pytest.mark.gpu
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+
+def _fd():
+    return importlib.import_module("4dgaussians_amd")
+
+
+def _model(n=6000, cfg="dynerf_default", seed=17, boost=1.0):
+    pc = synthetic.SynthModel(n, cfg, seed=seed)
+    with torch.no_grad():
+        pc._scaling.add_(boost)
+    return pc.to(torch.device("cuda:0"))
+
+
+def _render_and_grads(pc, cam, pipe, stage, w, **kw):
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    for p in pc.parameters():
+        p.grad = None
+    res = fd.render(cam, pc, pipe, torch.tensor([0.1, 0.2, 0.3], device=dev), stage=stage, **kw)
+    (res["render"] * w).sum().backward()
+    grads = {k: p.grad.clone() for k, p in pc.named_parameters() if p.grad is not None}
+    return res, grads, res["viewspace_points"].grad.clone()
+
+
+class _Pipe:
+    def __init__(self, sh=False, cov=False):
+        self.convert_SHs_python, self.compute_cov3D_python, self.debug = sh, cov, False
+
+
+@pytest.mark.parametrize("sh,cov", [(True, False), (False, True), (True, True)])
+def test_python_sh_and_python_cov3d_equal_native_path_coarse(sh, cov):
+    dev = torch.device("cuda:0")
+    pc = _model()
+    cam = synthetic.make_camera(240, 180, theta_deg=55.0, time=0.4).to(dev)
+    w = torch.randn(3, 180, 240, generator=torch.Generator().manual_seed(2)).to(dev)
+    a, ga, va = _render_and_grads(pc, cam, _Pipe(), "coarse", w)
+    b, gb, vb = _render_and_grads(pc, cam, _Pipe(sh, cov), "coarse", w)
+    assert (a["radii"] > 0).sum() > 1000
+    assert torch.equal(a["radii"], b["radii"])
+    d = (a["render"] - b["render"]).abs()
+    print(f"[sh={sh} cov={cov}] image max diff {float(d.max()):.2e} mean {float(d.mean()):.2e}")
+    assert float(d.max()) < 2e-5 and float(d.mean()) < 1e-6
+    assert float((a["depth"] - b["depth"]).abs().max()) < 2e-5
+    for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+        e = rel_l2(gb[k].cpu().numpy(), ga[k].cpu().numpy())
+        assert e < 1e-4, (k, e)
+    assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) < 1e-4
+
+
+def test_python_sh_fine_stage_runs_and_uses_canonical_features():
+    """In the fine stage the reference's python-SH branch evaluates the CANONICAL features at the CANONICAL positions
+    (pc.get_features / pc.get_xyz, :107-110) -- not the deformed ones.  Same here: image = native render with the SH head's
+    and position head's effect on the colour removed, i.e. equal to a render with override_color = those colours."""
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    pc = _model(4000)
+    cam = synthetic.make_camera(200, 152, theta_deg=10.0, time=0.7).to(dev)
+    bg = torch.zeros(3, device=dev)
+    a = fd.render(cam, pc, _Pipe(sh=True), bg, stage="fine")
+    feats = pc.get_features
+    dirs = pc.get_xyz - cam.camera_center.repeat(feats.shape[0], 1)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    cols = torch.clamp_min(fd.sh.eval_sh(3, feats.transpose(1, 2).view(-1, 3, 16), dirs) + 0.5, 0.0)
+    b = fd.render(cam, pc, _Pipe(), bg, stage="fine", override_color=cols)
+    assert torch.equal(a["render"], b["render"])
+    a["render"].sum().backward()
+    assert pc._features_rest.grad is not None and float(pc._features_rest.grad.abs().max()) > 0
+    assert float(pc._deformation.deformation_net.pos_deform[3].weight.grad.abs().max()) > 0
+
+
+def test_override_color_matches_direct_rasterizer_call():
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    pc = _model(3000)
+    cam = synthetic.make_camera(160, 120, theta_deg=-20.0).to(dev)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
+    cols = torch.rand(3000, 3, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
+    res = fd.render(cam, pc, _Pipe(), bg, stage="coarse", override_color=cols)
+    rs = fd.GaussianRasterizationSettings(120, 160, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
+                                          cam.full_proj_transform, 3, cam.camera_center, False, False)
+    img, radii, depth = fd.GaussianRasterizer(rs)(means3D=pc._xyz, means2D=torch.zeros_like(pc._xyz), opacities=torch.sigmoid(pc._opacity),
+                                                  colors_precomp=cols, scales=torch.exp(pc._scaling),
+                                                  rotations=torch.nn.functional.normalize(pc._rotation))
+    assert torch.equal(res["render"], img) and torch.equal(res["radii"], radii) and torch.equal(res["depth"], depth)
+    res["render"].sum().backward()
+    assert cols.grad is not None and float(cols.grad.abs().sum()) > 0 and pc._features_dc.grad is None
+
+
+def test_panoptic_sports_dict_camera_equals_camera_object():
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    pc = _model(3000)
+    cam = synthetic.make_camera(160, 120, theta_deg=75.0, time=0.25).to(dev)
+    bg = torch.zeros(3, device=dev)
+    a = fd.render(cam, pc, _Pipe(), bg, stage="fine")
+    rs = fd.GaussianRasterizationSettings(120, 160, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
+                                          cam.full_proj_transform, pc.active_sh_degree, cam.camera_center, False, False)
+    b = fd.render({"camera": rs, "time": 0.25}, pc, _Pipe(), bg, stage="fine", cam_type="PanopticSports")
+    for k in ("render", "depth", "radii"):
+        assert torch.equal(a[k], b[k]), k
+
+
+class _Foreign(torch.nn.Module):
+    """A deformation module render() does not know (stands for the reference's own scene.deformation.deform_network):
+    called as the reference calls it -- (means3D, scales, rotations, opacity, shs, time [N,1]) -> raw outputs."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
+        assert times_sel.shape == (point.shape[0], 1)
+        return self.inner(point, scales, rotations, opacity, shs, times_sel)
+
+
+def test_foreign_deformation_module_non_fused_fine_stage():
+    dev = torch.device("cuda:0")
+    pc = _model(5000)
+    cam = synthetic.make_camera(200, 152, theta_deg=140.0, time=0.55).to(dev)
+    w = torch.randn(3, 152, 200, generator=torch.Generator().manual_seed(3)).to(dev)
+    a, ga, va = _render_and_grads(pc, cam, _Pipe(), "fine", w)
+    inner = pc._deformation
+    pc._deformation = _Foreign(inner)                          # not an instance of fdgs.deform_network -> non-fused branch
+    b, gb, vb = _render_and_grads(pc, cam, _Pipe(), "fine", w)
+    assert torch.equal(a["radii"], b["radii"])
+    assert float((a["render"] - b["render"]).abs().max()) < 1e-5
+    for k, v in ga.items():
+        k2 = k.replace("_deformation.", "_deformation.inner.")
+        assert rel_l2(gb[k2].cpu().numpy(), v.cpu().numpy()) < 1e-4, k
+    assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) < 1e-4
+
+
+def test_hip_preprocess_cov3d_and_sh_colour_match_reference_python():
+    """geom fields of fdgs_preprocess_fwd against the fixture computed by the REFERENCE's python functions."""
+    import ctypes
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "raster_pins.npz"))
+    g = synthetic.make_gaussians(512, seed=31)
+    cam = synthetic.make_camera(400, 400, theta_deg=30.0).to(dev)
+    q = torch.nn.functional.normalize(g["rotation"]).to(dev)
+    shs = torch.cat([g["features_dc"], g["features_rest"]], 1).to(dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    L = fd._lib.lib()
+    for mod in (1.0, 0.7):
+        for deg in (3, 1):
+            rs = fd.GaussianRasterizationSettings(400, 400, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), mod,
+                                                  cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center, False, False)
+            _, radii, _, st = fd.rasterizer.rasterize_forward(rs, g["xyz"].to(dev), shs, None, torch.sigmoid(g["opacity"]).to(dev),
+                                                              torch.tensor(Z["cov.scales"], device=dev), q, None)
+            torch.cuda.synchronize()
+            vis = (radii > 0).cpu().numpy()
+            assert vis.sum() > 300
+            out = {}
+            for which, width in ((4, 6), (3, 4)):
+                p = ctypes.c_void_p()
+                assert L.fdgs_geom_field(ctypes.c_void_p(st.geom.data_ptr()), 512, which, ctypes.byref(p)) == 0
+                t = torch.empty(512 * width, device=dev)
+                assert hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), p, ctypes.c_size_t(512 * width * 4), ctypes.c_int(3)) == 0
+                out[which] = t.reshape(512, width).cpu().numpy()
+            ref = Z[f"cov3D.mod{mod}"]
+            scale = np.abs(ref[vis]).max(axis=1, keepdims=True)
+            assert (np.abs(out[4][vis] - ref[vis]) / scale).max() < 1e-5
+            np.testing.assert_allclose(out[3][vis, :3], Z[f"sh.colors.deg{deg}"][vis], rtol=0, atol=2e-6)

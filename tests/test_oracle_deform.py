@@ -60,6 +60,19 @@ def test_matches_golden(cfg):
     outs = DO.deform_forward(sd, args, *ins)
     for k, o in zip(("xyz", "scales", "rot", "opacity", "shs"), outs):
         assert torch.allclose(o, torch.tensor(z["out." + k]), rtol=1e-5, atol=1e-6), k
+    # backward: the reference modules' gradients of sum(out * w) stored next to the outputs
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    ins = [x.requires_grad_(True) for x in ins[:5]] + [ins[5]]
+    outs = DO.deform_forward(sd, args, *ins)
+    loss = sum((o * torch.tensor(z["w." + k])).sum() for k, o in zip(("xyz", "scales", "rot", "opacity", "shs"), outs))
+    gkeys = [k for k in z.files if k.startswith("grad.")]
+    wanted = [dict(zip(("in.xyz", "in.scales", "in.rot", "in.opacity", "in.shs"), ins))[k[5:]] if k.startswith("grad.in.") else sd[k[8:]]
+              for k in gkeys]
+    for k, g in zip(gkeys, torch.autograd.grad(loss, wanted, allow_unused=True)):
+        assert g is not None, k
+        assert torch.allclose(g, torch.tensor(z[k]), rtol=1e-4, atol=1e-5), (k, float((g - torch.tensor(z[k])).abs().max()))
 
 
 def test_border_and_flip_semantics():

@@ -119,3 +119,73 @@ def test_single_process_is_a_noop():
     assert par.frames_for_rank(160, 5, 0, 1) == 5
     p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.ones(3)
     assert par.allreduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))
+
+
+# ---- launcher-free multi-rank start (bench.py --gpus N without torch.distributed.run) ----
+def _spawned_job(path, backend):
+    """Runs in every rank started by parallel.spawn_local: the same entry sequence bench.py's run() uses."""
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    rank, world, dev = par.init_from_env(backend=backend)
+    seen = par.ranks_seen(dev)
+    times = par.gather_floats(10.0 + rank, dev)
+    # one rank lacks a gradient the other has: the has-grad mask makes the buckets identical on both ranks
+    a, b = torch.nn.Parameter(torch.zeros(5, device=dev)), torch.nn.Parameter(torch.zeros(3, device=dev))
+    a.grad = torch.full((5,), float(rank + 1), device=dev)
+    if rank == 1:
+        b.grad = torch.full((3,), 7.0, device=dev)
+    calls = par.allreduce_gradients([a, b])
+    par.barrier()
+    with open(f"{path}.{rank}", "w") as f:
+        f.write(repr((rank, world, seen, times, calls, a.grad.tolist(), b.grad.tolist(), str(dev))))
+
+
+def test_spawn_local_starts_ranks_and_rccl_style_handshake_on_gloo(tmp_path):
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    path = str(tmp_path / "out")
+    par.spawn_local(2, _spawned_job, (path, "gloo"))
+    for r in range(2):
+        rank, world, seen, times, calls, ga, gb, dev = eval(open(f"{path}.{r}").read())
+        assert (rank, world, seen) == (r, 2, 2) and times == [10.0, 11.0] and calls == 1
+        assert ga == [3.0] * 5 and gb == [7.0] * 3 and dev == "cpu"
+
+
+def _failing_job():
+    raise SystemExit(3)
+
+
+def test_spawn_local_reports_failed_ranks():
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    with pytest.raises(RuntimeError, match="exited non-zero"):
+        par.spawn_local(2, _failing_job)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` with WORLD_SIZE unset and fewer than N visible GPUs must stop with a clear message before
+    touching a device (on this CPU container 0 are visible; on a 1-GPU box the -m gpu twin below asks for 2)."""
+    import subprocess
+    import sys
+    n_vis = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_vis + 2)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and f"only {n_vis} GPU(s) visible" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_refuses_two_gpus_on_a_one_gpu_box():
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    test_bench_refuses_more_gpus_than_visible()
+
+
+@pytest.mark.gpu
+def test_two_gpu_ranks_meet_over_rccl(tmp_path):
+    """Real RCCL: two ranks, one GPU each, through the same spawn path bench.py --gpus 2 takes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    path = str(tmp_path / "out")
+    par.spawn_local(2, _spawned_job, (path, "nccl"))
+    for r in range(2):
+        rank, world, seen, times, calls, ga, gb, dev = eval(open(f"{path}.{r}").read())
+        assert (rank, world, seen) == (r, 2, 2) and ga == [3.0] * 5 and gb == [7.0] * 3 and dev == f"cuda:{r}"
