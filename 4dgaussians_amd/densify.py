@@ -198,3 +198,77 @@ def reset_opacity(pc):
         pc.optimizer.state[new] = st
     group["params"][0] = new
     pc._opacity = new
+
+
+# ---- spatial (Morton) ordering of the Gaussian set --------------------------------------------------------------------
+def morton_keys(xyz, lo=None, hi=None, bits=10):
+    """30-bit Morton (Z-order) code of every position: each axis quantised to `bits` bits inside [lo, hi] (default: the
+    bounding box of the points), bits interleaved x -> bit 0, y -> bit 1, z -> bit 2.  Elementwise torch integer ops."""
+    p = xyz.detach().float()
+    lo = p.min(0).values if lo is None else torch.as_tensor(lo, device=p.device, dtype=torch.float32)
+    hi = p.max(0).values if hi is None else torch.as_tensor(hi, device=p.device, dtype=torch.float32)
+    lo, hi = torch.minimum(lo, hi), torch.maximum(lo, hi)
+    q = ((p - lo) / (hi - lo).clamp_min(1e-20) * (2 ** bits)).clamp(0, 2 ** bits - 1).to(torch.int64)
+
+    def spread(v):          # abc -> a00b00c (10 bits -> 30)
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+
+
+def spatial_reorder(pc, perm=None):
+    """Re-order the Gaussian set along a Morton curve of the canonical positions (or by the given permutation).
+
+    The ORDER of the Gaussians carries no meaning anywhere in the reference (every per-Gaussian array is indexed in lock-step
+    and the rasterizer sorts by depth; only exact depth ties are broken by index), but it decides how the HexPlane kernels
+    touch memory: with neighbours in the array being neighbours in space, the lanes of a wave sample the same texel lines
+    (deformation forward gather) and the plane-gradient kernel can sum a whole workgroup's contributions to a small texel
+    window on the matrix cores before touching memory (csrc/deform.hip D4) instead of issuing one atomic line per
+    (Gaussian, corner).  The train loop calls this where the set changes anyway -- after densify / prune (every 100
+    iterations, scene/gaussian_model.py:409-500) -- so it costs nothing per frame.
+
+    Permutes, consistently: the six Parameters (new nn.Parameter objects in the same optimizer param groups, as densify
+    does), their Adam moments, xyz_gradient_accum / denom / max_radii2D / _deformation_accum / _deformation_table.  A model
+    without an optimizer (evaluation, synthetic scenes) has its Parameters' storage replaced in place.  Returns the
+    permutation (new row i = old row perm[i])."""
+    xyz = pc._xyz
+    if perm is None:
+        aabb = None
+        try:
+            aabb = pc._deformation.deformation_net.grid.aabb
+        except AttributeError:
+            pass
+        if aabb is not None and aabb.device == xyz.device:
+            keys = morton_keys(xyz, aabb[1], aabb[0])        # aabb[0] = max, aabb[1] = min (scene/hexplane.py:19-20)
+        else:
+            keys = morton_keys(xyz)
+        perm = torch.argsort(keys, stable=True)
+    perm = perm.to(xyz.device)
+    opt = getattr(pc, "optimizer", None)
+    groups = _groups(pc) if opt is not None else None
+    for n in GROUPS:
+        old = getattr(pc, ATTR[n])
+        data = old.detach().index_select(0, perm).contiguous()
+        if opt is None:
+            with torch.no_grad():
+                old.data = data
+            old.grad = None
+            continue
+        new = nn.Parameter(data.requires_grad_(True))
+        st = opt.state.get(old, None)
+        if st is not None:
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k] = st[k].index_select(0, perm).contiguous()
+            del opt.state[old]
+            opt.state[new] = st
+        groups[n]["params"][0] = new
+        setattr(pc, ATTR[n], new)
+    for name in ("xyz_gradient_accum", "denom", "max_radii2D", "_deformation_accum", "_deformation_table"):
+        t = getattr(pc, name, None)
+        if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == perm.shape[0]:
+            setattr(pc, name, t.index_select(0, perm.to(t.device)).contiguous())
+    return perm

