@@ -1571,6 +1571,458 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
     }
 }
 
+// ------------------------------------------------------------------------------------------------ D4, matrix-core splat
+// The plane gradient is a SPLAT: dP[texel][c] = sum_n w_n(texel) * dv_n[c] -- per plane a (sparse) [texels x Gaussians]
+// weight matrix times the dense [Gaussians x channels] matrix dv.  When the Gaussian set is kept in spatial (Hilbert)
+// order (fdgs.densify.spatial_reorder), the G consecutive Gaussians a workgroup takes at a time fall into a window of a
+// few texels per axis, and the product over that window is a small DENSE GEMM: it runs on v_mfma_f32_16x16x4_f32
+// (M = 16 texels of one window row, N = 16 channels, K = 4 Gaussians; A = wx(texel) * wy(row) built on the fly from three
+// numbers per Gaussian and axis), and memory sees ONE atomic line per touched texel of the window instead of one per
+// (Gaussian, corner): 24 -> ~6 line-ops per Gaussian at BASELINE config 4.  (Float atomics cost per 64-B line-op,
+// ~20 G/s on MI355X whatever the lane count; and with neighbours in the array being neighbours in space the per-corner
+// atomics of the kernel above collide on the same lines and get SLOWER, 0.42 -> 0.69 ms.)
+//   phase S0  one thread per Gaussian: normalised coordinates -> LDS, window origin per (level, axis) by LDS atomicMin/Max
+//   phase S   (per level) lanes <-> (x-corner, channel) as above: sample the six planes, dv_k[c] = dfeat[c] * prod_{k'!=k} v_k'[c]
+//             -> LDS, coordinate gradient -> LDS; a Gaussian outside a plane's 16 x 16 window (unsorted input, sparse
+//             levels) takes the direct atomics of the kernel above for that plane
+//   phase M   (per level) wave k < 6 owns plane k: spatial planes accumulate the window in 16 x 4 accumulator registers
+//             (rows no Gaussian of the k-step touches are skipped, wave-uniform) and flush it with one atomic per touched
+//             texel line; the time planes (one frame time for all Gaussians: 1-D rows) accumulate 16-texel tiles and add
+//             them to the workgroup's private LDS row with plain read-add-writes (one owner wave: no LDS float atomics,
+//             which run at 0.33 lanes/clk/CU), flushed once per workgroup with the two time weights.
+// Every path adds the same products; only the summation order differs from the per-corner atomics.
+constexpr int PGM_THREADS = 512;     // 8 waves, 256 VGPRs each: one workgroup per CU (LDS), the sampling pass needs ~150 registers
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+#ifdef FDGS_PROFILE_D4
+#define D4_TICK(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[ph] += t_ - prof_t; prof_t = t_; } while (0)
+#else
+#define D4_TICK(ph) do { } while (0)
+#endif
+struct PlaneGradMArgs {
+    PlaneGradArgs g;
+    unsigned long long* prof;
+    int nchunks;
+    int off_dv, off_q, off_desc, off_dq, off_org;   // float offsets into the dynamic LDS
+};
+
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int C>
+__global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(PlaneGradMArgs ma) {
+    const PlaneGradArgs& a = ma.g;
+    const fdgs_deform_params& p = a.p;
+    extern __shared__ float4 pgm_lds4[];
+    float* lds = reinterpret_cast<float*>(pgm_lds4);
+    constexpr int G = 2048 / C;                       // Gaussians per chunk = per sampling pass of the workgroup
+    constexpr int NW = PGM_THREADS / 64;
+    constexpr int CG = C / 4, LPG = 2 * CG, GPW = 64 / LPG;   // sampling pass: lane = (Gaussian, x-corner, group of 4 channels)
+    constexpr int NB = G / (GPW * NW);                        // sampling passes per chunk
+    static_assert(NB * GPW * NW == G, "whole sampling passes");
+    constexpr int LPGO = 2 * C, GPWO = 64 / LPGO;     // miss pass (per-corner atomics): lane = (Gaussian, x-corner, channel)
+    constexpr int NH = C / 16;                        // channel halves of 16
+    float* s_dv = lds + ma.off_dv;                    // [6][G][C]
+    float* s_q = lds + ma.off_q;                      // [3][G] normalised coordinates
+    float4* s_ax = reinterpret_cast<float4*>(lds + ma.off_desc);    // [3][G] {i0 (int bits), weight at i0, weight at i0 + 1, -} of this level
+    uint32_t* s_in = reinterpret_cast<uint32_t*>(lds + ma.off_desc + 12 * G);   // [G] bit k: plane k of this level goes through its window
+    float* s_dq = lds + ma.off_dq;                    // [G][3]
+    float* s_part = lds + ma.off_org;                 // [G / 64][3] per-wave minima of the coordinates
+    // Gaussians of the chunk binned by window row, once per row axis (y for plane (x,y); z for planes (x,z), (y,z)): the
+    // matrix-core loop walks one row's list at a time, so its accumulators are static registers and a step is two MFMAs
+    int* s_cnt_all = reinterpret_cast<int*>(lds + ma.off_org + 16);  // [2 (level parity)][40]: [2][16] row counts + miss count; zeroed one level ahead
+    uint32_t* s_miss = reinterpret_cast<uint32_t*>(lds + ma.off_org + 96);     // [G] Gaussian | planes that take the per-corner atomics << 8
+    uint8_t* s_list = reinterpret_cast<uint8_t*>(lds + ma.off_org + 96 + G);   // [2][16][G]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane % CG, xc = (lane / CG) & 1, gl_s = wave * GPW + lane / LPG;
+    // window of the previous phase, kept in registers: its atomics are issued at the START of the next matrix-core loop and drain
+    // while that loop runs (loads, stores and no-return atomics share one in-order counter: a sampling load issued right after a
+    // flush could only be waited for together with the whole flush)
+    f32x4v acc[9];
+    uint32_t pend_rows = 0;
+    float* pend_dP = nullptr;
+    int pend_ox = 0, pend_oy = 0, pend_Wd = 0, pend_Hd = 0, pend_hf = 0;
+    for (int i = tid; i < a.lds_floats; i += PGM_THREADS) lds[i] = 0.f;     // private time rows
+#ifdef FDGS_PROFILE_D4
+    unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_t0 = prof_t;
+#endif
+    const int c_begin = (int)((long long)blockIdx.x * ma.nchunks / gridDim.x);         // contiguous chunks: spatial locality
+    const int c_end = (int)((long long)(blockIdx.x + 1) * ma.nchunks / gridDim.x);
+    const float tq = p.time_scalar;
+    for (int chunk = c_begin; chunk < c_end; chunk++) {
+        const int n0 = chunk * G;
+        // ---- S0: coordinates -> LDS, per-axis minimum over the chunk (the texel index is monotonic in the coordinate, so the
+        // window origin of every level follows from the three minima)
+        if (tid >= PGM_THREADS - 40) s_cnt_all[tid - (PGM_THREADS - 40)] = 0;
+        if (tid < G) {
+            const int n = n0 + tid;
+            const bool live = n < p.N;
+            const int nn = live ? n : p.N - 1;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float q = (p.xyz[3 * (size_t)nn + i] - p.aabb[i]) * a.sc.inv2[i] - 1.0f;
+                s_q[i * G + tid] = q;
+                s_dq[tid * 3 + i] = 0.f;
+                float m = live ? q : 3.0e38f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+                if (lane == 0) s_part[wave * 3 + i] = m;
+            }
+        }
+        __syncthreads();
+        float qmin[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float m = s_part[i];
+#pragma unroll
+            for (int w = 1; w < G / 64; w++) m = fminf(m, s_part[w * 3 + i]);
+            qmin[i] = m;
+        }
+        D4_TICK(0);
+        for (int lvl = 0; lvl < p.L; lvl++) {
+            const int org0 = axis_sample(qmin[0], p.res[lvl][0]).i0, org1 = axis_sample(qmin[1], p.res[lvl][1]).i0;
+            const int org2 = axis_sample(qmin[2], p.res[lvl][2]).i0;
+            const int lo0 = a.lds_off[lvl][0], lo1 = a.lds_off[lvl][1], lo2 = a.lds_off[lvl][2];
+            int* s_cnt = s_cnt_all + (lvl & 1) * 40;      // (zeroed during the previous level's M phase / in S0)
+            // ---- S: lane = (Gaussian, x-corner, 4 channels): 16-byte texel loads, the per-Gaussian index / weight arithmetic is
+            // shared by four channels.  dv -> LDS, coordinate gradient -> LDS, window bookkeeping.
+#pragma nounroll
+            for (int b = 0; b < NB; b++) {
+                const int gl = b * (GPW * NW) + gl_s;
+                const int n = n0 + gl;
+                const bool live = n < p.N;
+                float q[4];
+                q[0] = s_q[gl]; q[1] = s_q[G + gl]; q[2] = s_q[2 * G + gl]; q[3] = tq;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 df = *reinterpret_cast<const float4*>(a.DFEAT + (size_t)(live ? n : p.N - 1) * a.F + lvl * C + 4 * cg);
+                if (!live) df = z4;
+                float4 vk[6], sk[6], tk[6];
+                float dsx[6], dsy[6];
+                AxisSample S[4];
+#pragma unroll
+                for (int ax4 = 0; ax4 < 4; ax4++) S[ax4] = axis_sample(q[ax4], p.res[lvl][ax4]);
+#pragma unroll
+                for (int grp = 0; grp < 2; grp++) {       // three planes (six 16-byte texel requests) at a time: bounded registers
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        const int k = 3 * grp + kk;
+                        int ax, bx;
+                        plane_axes(k, ax, bx);
+                        const int Wd = p.res[lvl][ax];
+                        const AxisSample sx = S[ax], sy = S[bx];
+                        const int xi = xc ? sx.i1 : sx.i0;
+                        const float wx = xc ? sx.w1 : sx.w0;
+                        const uint32_t oA = (uint32_t)((sy.i0 * Wd + xi) * C + 4 * cg), oB = (uint32_t)((sy.i1 * Wd + xi) * C + 4 * cg);
+                        const char* Pb = reinterpret_cast<const char*>(p.planes[lvl][k]);
+                        const float4 v0 = *reinterpret_cast<const float4*>(Pb + oA * 4u);
+                        const float4 v1 = *reinterpret_cast<const float4*>(Pb + oB * 4u);
+                        sk[k] = make_float4(sy.w0 * v0.x + sy.w1 * v1.x, sy.w0 * v0.y + sy.w1 * v1.y, sy.w0 * v0.z + sy.w1 * v1.z, sy.w0 * v0.w + sy.w1 * v1.w);
+                        tk[k] = make_float4(wx * (v1.x - v0.x), wx * (v1.y - v0.y), wx * (v1.z - v0.z), wx * (v1.w - v0.w));
+                        const float4 part = f4scale(sk[k], wx);
+                        vk[k] = make_float4(part.x + __shfl_xor(part.x, CG, 64), part.y + __shfl_xor(part.y, CG, 64),
+                                            part.z + __shfl_xor(part.z, CG, 64), part.w + __shfl_xor(part.w, CG, 64));
+                        dsx[k] = sx.dscale; dsy[k] = sy.dscale;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float4 suf[6];        // suf[k] = prod_{k' > k} v_k'; the prefix product runs along with the plane loop below
+                suf[5] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+                for (int k = 4; k >= 0; k--) suf[k] = f4mul(suf[k + 1], vk[k + 1]);
+                float4 pre = suf[5];
+                // which planes of this Gaussian go through a window: spatial planes when both axes lie within 15 texels of the
+                // chunk's minimum; time planes (private rows) when the texel pair lies in the two 16-texel tiles that start at
+                // the tile of the chunk's minimum.  Anything else takes the per-corner atomics in the miss pass below.
+                const int d0 = S[0].i0 - org0, d1 = S[1].i0 - org1, d2 = S[2].i0 - org2;
+                const bool in0 = d0 <= 14, in1 = d1 <= 14, in2 = d2 <= 14;
+                const bool t0 = lo0 >= 0 && S[0].i0 - (org0 & ~15) <= 30, t1 = lo1 >= 0 && S[1].i0 - (org1 & ~15) <= 30;
+                const bool t2 = lo2 >= 0 && S[2].i0 - (org2 & ~15) <= 30;
+                uint32_t inw = 0, want = 0;
+                if (live) {
+                    inw = (in0 && in1 ? 1u : 0u) | (in0 && in2 ? 2u : 0u) | (t0 ? 4u : 0u) | (in1 && in2 ? 8u : 0u) | (t1 ? 16u : 0u) | (t2 ? 32u : 0u);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) want |= a.d_planes[lvl][k] ? (1u << k) : 0u;
+                }
+                inw &= want;
+                const uint32_t miss = want & ~inw;
+                float dq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    int ax, bx;
+                    plane_axes(k, ax, bx);
+                    const float4 dv = f4mul(df, f4mul(pre, suf[k]));
+                    pre = f4mul(pre, vk[k]);
+                    const bool wk = (inw >> k) & 1u;      // (element-wise selects: a float4 ?: goes through scratch memory)
+                    if (xc == 0)
+                        *reinterpret_cast<float4*>(s_dv + (k * G + gl) * C + 4 * cg) = make_float4(wk ? dv.x : 0.f, wk ? dv.y : 0.f, wk ? dv.z : 0.f, wk ? dv.w : 0.f);
+                    const float gx = (xc ? 1.f : -1.f) * f4dot(dv, sk[k]) * dsx[k];
+                    const float gy = f4dot(dv, tk[k]) * dsy[k];
+                    if (ax < 3) dq[ax] += gx;
+                    if (bx < 3) dq[bx] += gy;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    float v = dq[i];
+#pragma unroll
+                    for (int o = 1; o < LPG; o <<= 1) v += __shfl_xor(v, o, 64);
+                    dq[i] = v;
+                }
+                if ((lane % LPG) == 0) {
+                    s_in[gl] = inw;
+                    if (inw & 1u) s_list[(0 * 16 + d1) * G + atomicAdd(&s_cnt[d1], 1)] = (uint8_t)gl;            // rows of plane (x,y): y
+                    if (inw & 10u) s_list[(1 * 16 + d2) * G + atomicAdd(&s_cnt[16 + d2], 1)] = (uint8_t)gl;      // rows of (x,z), (y,z): z
+                    if (miss) s_miss[atomicAdd(&s_cnt[32], 1)] = (uint32_t)gl | (miss << 8);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const bool edge = S[i].i1 == S[i].i0;      // clamped at the last texel: both corners are the same texel
+                        s_ax[i * G + gl] = make_float4(__int_as_float(S[i].i0), edge ? S[i].w0 + S[i].w1 : S[i].w0, edge ? 0.f : S[i].w1, 0.f);
+                        s_dq[gl * 3 + i] += dq[i];
+                    }
+                }
+            }
+            D4_TICK(1);
+            __syncthreads();
+            D4_TICK(2);
+            if (wave == NW - 1 && lane < 40) s_cnt_all[((lvl + 1) & 1) * 40 + lane] = 0;
+            // ---- M: waves 0..5 = (spatial plane, half of the window rows), waves 6, 7 = time planes
+            const int gk = lane >> 4, il = lane & 15;         // Gaussian of the k-step / texel of the tile (A), channel (B)
+            if (wave < 6) {
+                const int pi = wave >> 1, hh = wave & 1;
+                const int k = pi == 2 ? 3 : pi;
+                float* dP = a.d_planes[lvl][k];
+                if (dP) {
+                    int ax, bx;
+                    plane_axes(k, ax, bx);
+                    const int ox = ax == 0 ? org0 : org1, oy = bx == 1 ? org1 : org2;
+                    const int bin = k == 0 ? 0 : 1;
+                    const uint32_t kbit = 1u << k;
+#pragma nounroll
+                    for (int hf = 0; hf < NH; hf++) {
+                        // the previous window of this wave: accumulator register j of lane (gk, il) is texel x = ox + 4 gk + j of window
+                        // row 8 hh + rr, channel il
+                        if (pend_rows) {
+#pragma unroll
+                            for (int rr = 0; rr < 9; rr++) {
+                                if ((pend_rows >> rr) & 1u) {
+                                    const int y = pend_oy + rr;
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        const int x = pend_ox + 4 * gk + j;
+                                        const float v = acc[rr][j];
+                                        if (v != 0.f && x < pend_Wd && y < pend_Hd) atomicAdd(&pend_dP[((size_t)y * pend_Wd + x) * C + pend_hf * 16 + il], v);
+                                    }
+                                }
+                            }
+                        }
+                        D4_TICK(4);
+#pragma unroll
+                        for (int r = 0; r < 9; r++) acc[r] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                        uint32_t rows_any = 0;
+#pragma unroll
+                        for (int rr = 0; rr < 8; rr++) {
+                            const int r = 8 * hh + rr;                 // list of window row r feeds rows r and r + 1 (r <= 14)
+                            const int nr = r <= 14 ? s_cnt[bin * 16 + r] : 0;
+                            const uint8_t* lst = s_list + (bin * 16 + r) * G;
+                            // two steps (8 Gaussians) per iteration; the list bytes of the next iteration are requested before this
+                            // iteration's operands, and all operand requests before the first MFMA
+                            int ga = gk < nr ? (int)lst[gk] : 0, gb = 4 + gk < nr ? (int)lst[4 + gk] : 0;
+                            for (int j0 = 0; j0 < nr; j0 += 8) {
+                                const bool ha = j0 + gk < nr, hb = j0 + 4 + gk < nr;
+                                const int gla = ga, glb = gb;
+                                ga = j0 + 8 + gk < nr ? (int)lst[j0 + 8 + gk] : 0;
+                                gb = j0 + 12 + gk < nr ? (int)lst[j0 + 12 + gk] : 0;
+                                const float4 cxa = s_ax[ax * G + gla], cya = s_ax[bx * G + gla];
+                                const float4 cxb = s_ax[ax * G + glb], cyb = s_ax[bx * G + glb];
+                                const uint32_t cia = s_in[gla], cib = s_in[glb];
+                                const float bra = s_dv[(k * G + gla) * C + hf * 16 + il], brb = s_dv[(k * G + glb) * C + hf * 16 + il];
+                                __builtin_amdgcn_sched_barrier(0);
+                                // (planes (x,z) and (y,z) share the z lists: an entry counts for this plane only if its own window test passed)
+                                const float bva = (ha && (cia & kbit)) ? bra : 0.f, bvb = (hb && (cib & kbit)) ? brb : 0.f;
+                                const int dxa = __float_as_int(cxa.x) - ox, dxb = __float_as_int(cxb.x) - ox;
+                                const float wxa = il == dxa ? cxa.y : (il == dxa + 1 ? cxa.z : 0.f);
+                                const float wxb = il == dxb ? cxb.y : (il == dxb + 1 ? cxb.z : 0.f);
+                                acc[rr] = mfma16(wxa * cya.y, bva, acc[rr]);
+                                acc[rr + 1] = mfma16(wxa * cya.z, bva, acc[rr + 1]);
+                                acc[rr] = mfma16(wxb * cyb.y, bvb, acc[rr]);
+                                acc[rr + 1] = mfma16(wxb * cyb.z, bvb, acc[rr + 1]);
+                            }
+                            if (nr > 0) rows_any |= 3u << rr;
+                        }
+                        pend_rows = rows_any; pend_dP = dP; pend_ox = ox; pend_oy = oy + 8 * hh; pend_Wd = p.res[lvl][ax]; pend_Hd = p.res[lvl][bx];
+                        pend_hf = hf;
+                        D4_TICK(3);
+                    }
+                }
+            } else {
+                for (int slot = wave == 6 ? 0 : 2; slot < (wave == 6 ? 2 : 3); slot++) {
+                    const int k = slot == 0 ? 2 : (slot == 1 ? 4 : 5);
+                    const int loff = slot == 0 ? lo0 : (slot == 1 ? lo1 : lo2);
+                    if (loff < 0) continue;
+                    const int ax = slot;
+                    const int Wd = p.res[lvl][ax];
+                    float* row = lds + loff;                              // [Wd][C] private to the workgroup
+                    const int x0 = (slot == 0 ? org0 : (slot == 1 ? org1 : org2)) & ~15;   // two 16-texel tiles from the tile of the chunk's minimum
+#pragma nounroll
+                    for (int hf = 0; hf < NH; hf++) {
+                        f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4v{0.f, 0.f, 0.f, 0.f};
+                        float4 nxa = s_ax[ax * G + gk], nxb = s_ax[ax * G + 4 + gk];
+                        float nba = s_dv[(k * G + gk) * C + hf * 16 + il], nbb = s_dv[(k * G + 4 + gk) * C + hf * 16 + il];
+                        for (int ks = 0; ks < G / 4; ks += 2) {
+                            const float4 cxa = nxa, cxb = nxb;
+                            const float bva = nba, bvb = nbb;
+                            const int gn = 4 * (ks + 2 < G / 4 ? ks + 2 : ks) + gk;
+                            nxa = s_ax[ax * G + gn]; nxb = s_ax[ax * G + gn + 4];
+                            nba = s_dv[(k * G + gn) * C + hf * 16 + il]; nbb = s_dv[(k * G + gn + 4) * C + hf * 16 + il];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int ra = __float_as_int(cxa.x) - x0, rb = __float_as_int(cxb.x) - x0;    // (Gaussians outside the two tiles have dv = 0)
+                            acc0 = mfma16(il == ra ? cxa.y : (il == ra + 1 ? cxa.z : 0.f), bva, acc0);
+                            acc1 = mfma16(il + 16 == ra ? cxa.y : (il + 16 == ra + 1 ? cxa.z : 0.f), bva, acc1);
+                            acc0 = mfma16(il == rb ? cxb.y : (il == rb + 1 ? cxb.z : 0.f), bvb, acc0);
+                            acc1 = mfma16(il + 16 == rb ? cxb.y : (il + 16 == rb + 1 ? cxb.z : 0.f), bvb, acc1);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int xa = x0 + 4 * gk + j, xb = xa + 16;
+                            if (xa < Wd && acc0[j] != 0.f) row[xa * C + hf * 16 + il] += acc0[j];
+                            if (xb < Wd && acc1[j] != 0.f) row[xb * C + hf * 16 + il] += acc1[j];
+                        }
+                    }
+                }
+                D4_TICK(5);
+            }
+            // ---- miss pass: the (Gaussian, plane) pairs outside their window take the per-corner atomics, lane = (Gaussian, x-corner,
+            // channel) so that every atomic instruction covers whole texel lines.  Rare on spatially ordered input; on unordered input
+            // it is the whole plane gradient (the windows only catch what happens to lie near the chunk's minimum).  The time rows it
+            // touches are LDS atomics on rows that only their owner wave (above) writes with plain adds: this pass therefore runs
+            // after a barrier when a time plane is among the misses.
+            const int nmiss = s_cnt[32];
+            if (nmiss > 0) {
+                __syncthreads();       // (uniform: nmiss is the same for every thread)
+                const int cho = lane % C, xco = (lane / C) & 1, gso = lane / LPGO;
+                for (int e0 = 0; e0 < nmiss; e0 += NW * GPWO) {
+                    const int e = e0 + wave * GPWO + gso;
+                    if (e < nmiss) {
+                        const uint32_t ent = s_miss[e];
+                        const int gl = (int)(ent & 0xFFu);
+                        const uint32_t mm = ent >> 8;
+                        const int n = n0 + gl;
+                        float q[4];
+                        q[0] = s_q[gl]; q[1] = s_q[G + gl]; q[2] = s_q[2 * G + gl]; q[3] = tq;
+                        const float dfo = a.DFEAT[(size_t)n * a.F + lvl * C + cho];
+                        float vko[6], wA[6], wB[6], wX[6];
+                        uint32_t oA[6], oB[6], oX[6];
+                        AxisSample S[4];
+#pragma unroll
+                        for (int ax4 = 0; ax4 < 4; ax4++) S[ax4] = axis_sample(q[ax4], p.res[lvl][ax4]);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            int ax, bx;
+                            plane_axes(k, ax, bx);
+                            const int Wd = p.res[lvl][ax];
+                            const AxisSample sx = S[ax], sy = S[bx];
+                            const int xi = xco ? sx.i1 : sx.i0;
+                            const float wx = xco ? sx.w1 : sx.w0;
+                            oX[k] = (uint32_t)(xi * C + cho);
+                            oA[k] = (uint32_t)((sy.i0 * Wd + xi) * C + cho);
+                            oB[k] = (uint32_t)((sy.i1 * Wd + xi) * C + cho);
+                            const char* Pb = reinterpret_cast<const char*>(p.planes[lvl][k]);
+                            const float v0 = *reinterpret_cast<const float*>(Pb + oA[k] * 4u);
+                            const float v1 = *reinterpret_cast<const float*>(Pb + oB[k] * 4u);
+                            float part = wx * (sy.w0 * v0 + sy.w1 * v1);
+                            if (C == 16) {
+                                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                                part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            } else {
+                                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                                part = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            }
+                            vko[k] = part;
+                            wX[k] = wx; wA[k] = wx * sy.w0; wB[k] = wx * sy.w1;
+                        }
+                        float preo[6], sufo[6];
+                        preo[0] = 1.f; sufo[5] = 1.f;
+#pragma unroll
+                        for (int k = 1; k < 6; k++) preo[k] = preo[k - 1] * vko[k - 1];
+#pragma unroll
+                        for (int k = 4; k >= 0; k--) sufo[k] = sufo[k + 1] * vko[k + 1];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            if ((mm >> k) & 1u) {
+                                const float dv = dfo * preo[k] * sufo[k];
+                                const int slot = time_plane_slot(k);
+                                const int loff = slot == 0 ? lo0 : (slot == 1 ? lo1 : (slot == 2 ? lo2 : -1));
+                                if (loff >= 0) {
+                                    atomicAdd(&lds[loff + oX[k]], dv * wX[k]);      // private time row (ds_add_f32)
+                                } else {
+                                    float* dP = a.d_planes[lvl][k];
+                                    atomicAdd(&dP[oA[k]], dv * wA[k]);
+                                    atomicAdd(&dP[oB[k]], dv * wB[k]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            D4_TICK(6);
+        }
+        if (a.d_xyz && tid < G && n0 + tid < p.N) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.d_xyz[3 * (size_t)(n0 + tid) + i] += s_dq[tid * 3 + i] * a.sc.inv2[i];
+        }
+        __syncthreads();
+        D4_TICK(7);
+    }
+    if (wave < 6 && pend_rows) {          // the last window of this wave
+        const int gk = lane >> 4, il = lane & 15;
+#pragma unroll
+        for (int rr = 0; rr < 9; rr++) {
+            if ((pend_rows >> rr) & 1u) {
+                const int y = pend_oy + rr;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int x = pend_ox + 4 * gk + j;
+                    const float v = acc[rr][j];
+                    if (v != 0.f && x < pend_Wd && y < pend_Hd) atomicAdd(&pend_dP[((size_t)y * pend_Wd + x) * C + pend_hf * 16 + il], v);
+                }
+            }
+        }
+    }
+#ifdef FDGS_PROFILE_D4
+    if (ma.prof && lane == 0 && blockIdx.x < 64) {
+        unsigned long long* out = ma.prof + (size_t)(blockIdx.x * NW + wave) * 10;
+        for (int i = 0; i < 8; i++) out[i] = prof_acc[i];
+        out[9] = __builtin_amdgcn_s_memtime() - prof_t0;
+    }
+#endif
+    if (a.lds_floats == 0) return;
+    // flush the private time rows: rows t0, t1 of plane (axis, t) get the row scaled by the two time weights
+    for (int lvl = 0; lvl < p.L; lvl++) {
+        const AxisSample st = axis_sample(p.time_scalar, p.res[lvl][3]);
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+            const int loff = a.lds_off[lvl][slot];
+            if (loff < 0) continue;
+            const int k = slot == 0 ? 2 : (slot == 1 ? 4 : 5);
+            const int Wd = p.res[lvl][slot];
+            float* dP = a.d_planes[lvl][k];
+            float* r0 = dP + (size_t)st.i0 * Wd * C;
+            float* r1 = dP + (size_t)st.i1 * Wd * C;
+            for (int i = tid; i < Wd * C; i += PGM_THREADS) {
+                const float v = lds[loff + i];
+                if (v != 0.f) {
+                    atomicAdd(&r0[i], v * st.w0);
+                    atomicAdd(&r1[i], v * st.w1);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int validate_deform(const fdgs_deform_params* p) {
     FDGS_REQUIRE(p != nullptr, "params is NULL");
@@ -1877,10 +2329,16 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     for (int l = 0; l < p->L; l++)
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
+        // matrix-core splat (default whenever one frame time is shared by all Gaussians, i.e. on the render() path): the
+        // fixed LDS part is the dv tile, coordinates, descriptors; the time rows get what is left of the 160 KB
+        const bool use_mfma = !p->time && tunable("FDGS_D4_MFMA", 1);
+        const int Gc = 2048 / p->C;
+        const int fixed_floats = 6 * 2048 + 3 * Gc + 13 * Gc + 3 * Gc + (96 + 9 * Gc) + 64;
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
         // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
         // atomics on ~128 hot lines, is 4x slower than scattered atomics)
-        const int lds_budget = tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0;
+        const int lds_budget = use_mfma ? 160 * 1024 - fixed_floats * 4
+                                        : (tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0);
         int used = 0;
         for (int l = 0; l < FDGS_MAX_LEVELS; l++)
             for (int sl = 0; sl < 3; sl++) ga.lds_off[l][sl] = -1;
@@ -1896,6 +2354,59 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             }
         }
         ga.lds_floats = used;
+        if (use_mfma) {
+            PlaneGradMArgs ma{};
+            ma.g = ga;
+            ma.prof = nullptr;
+#ifdef FDGS_PROFILE_D4
+            static unsigned long long* prof_dev = nullptr;
+            const size_t prof_n = 64 * 16 * 10;   // (8 waves per workgroup are used)
+            if (!prof_dev) (void)hipMalloc(&prof_dev, prof_n * sizeof(unsigned long long));
+            (void)hipMemsetAsync(prof_dev, 0, prof_n * sizeof(unsigned long long), stream);
+            ma.prof = prof_dev;
+#endif
+            ma.nchunks = cdiv(p->N, Gc);
+            int o = (used + 63) / 64 * 64;
+            ma.off_dv = o; o += 6 * 2048;
+            ma.off_q = o; o += 3 * Gc;
+            ma.off_desc = o; o += 13 * Gc;   // [3][G] float4 axis descriptors + [G] window masks
+            ma.off_dq = o; o += 3 * Gc;
+            ma.off_org = o; o += 96 + 9 * Gc;   // per-wave minima, row counters, row lists
+            const size_t lds_bytes = (size_t)o * 4;
+            int blocks = tunable("FDGS_PGM_WGS", 256);
+            if (blocks > ma.nchunks) blocks = ma.nchunks;
+            static bool raised16 = false, raised32 = false;
+            bool& raised = p->C == 16 ? raised16 : raised32;
+            if (!raised) {
+                const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16>)
+                                            : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32>);
+                FDGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+            if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16>), dim3(blocks), dim3(PGM_THREADS), lds_bytes, stream, ma); }
+            else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32>), dim3(blocks), dim3(PGM_THREADS), lds_bytes, stream, ma); }
+            FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
+#ifdef FDGS_PROFILE_D4
+            {
+                static int reports = 0;
+                if (reports++ == 5) {
+                    std::vector<unsigned long long> hbuf(prof_n);
+                    (void)hipStreamSynchronize(stream);
+                    (void)hipMemcpy(hbuf.data(), prof_dev, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                    const char* nm[8] = {"S0+bar", "S", "bar(S)", "M.sp.loop", "M.sp.flush", "M.time", "bar(M)", "dxyz+bar"};
+                    for (int wv : {0, 1, 2, 5, 6, 7}) {
+                        double sum[10] = {0}; int cnt = 0;
+                        for (int b = 0; b < 64; b++) { const unsigned long long* r = &hbuf[(size_t)(b * 8 + wv) * 10]; if (!r[9]) continue; cnt++; for (int i = 0; i < 10; i++) sum[i] += (double)r[i]; }
+                        if (!cnt) continue;
+                        fprintf(stderr, "[D4 profile] wave %2d (total %.0f cyc, s_memtime units):", wv, sum[9] / cnt);
+                        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * sum[i] / sum[9]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+#endif
+            return FDGS_OK;
+        }
         const int gpb = (PG_THREADS / 64) * (64 / (2 * p->C));       // Gaussians per workgroup iteration
         int nwg = tunable("FDGS_PG_WGS", 512);                        // ~2 workgroups per CU
         int per_block = cdiv(p->N, nwg);

@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary full-iteration measurement")
+    ap.add_argument("--order", default="hilbert", choices=["hilbert", "morton", "random"],
+                    help="order of the Gaussian set: hilbert = as fdgs.densify.spatial_reorder leaves it after every densification "
+                         "(the order the train loop runs in), random = the generator's order")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = median")
     args = ap.parse_args()
 
@@ -98,6 +101,8 @@ def run(args):
     L = fdgs._lib.lib()
     N, W, H, dcfg = WORKLOADS[args.workload]
     pc = syn.SynthModel(N, dcfg, seed=6666, device=dev)
+    if args.order != "random":
+        fdgs.densify.spatial_reorder(pc, curve=args.order)
     pipe = syn.PipelineParams()
     bg = torch.zeros(3, device=dev)
     cams = [c.to(dev) for c in syn.orbit_cameras(W, H, n=160)]
@@ -254,7 +259,7 @@ def run(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "lib_sha16": lib_sha16(fdgs),
             "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
-                       "frames_per_step": world, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
+                       "frames_per_step": world, "gaussian_order": args.order, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "train_iteration": train,
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "timed_regions_ms_per_step": [round(x / args.steps * 1e3, 4) for x in regions], "value_is": "median of the timed regions",

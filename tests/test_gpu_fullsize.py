@@ -34,11 +34,13 @@ def _groups(grads):
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 @pytest.mark.parametrize("with_depth", [False])
-def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth):
+def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert"):
     fd = importlib.import_module("4dgaussians_amd")
     dev = torch.device("cuda:0")
     N, W, H, dcfg = CONFIGS[name]
-    pc = synthetic.SynthModel(N, dcfg, seed=6666)                  # the bench scene
+    pc = synthetic.SynthModel(N, dcfg, seed=6666)                  # the bench scene ...
+    if order != "random":
+        fd.densify.spatial_reorder(pc, curve=order)                # ... in the order bench.py runs it (CPU tensors: torch ops)
     cam = synthetic.orbit_cameras(W, H, n=160)[8]
     o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth)
     pc = pc.to(dev)
@@ -80,5 +82,35 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth):
 
 
 def test_render_parity_with_depth_gradient_at_config4():
-    """Same as above with a gradient on the depth output too (the DEPTH instantiation of the blending backward)."""
-    test_render_fwd_bwd_parity_at_baseline_size("cfg4_dynerf_300k_1352x1014", True)
+    """Same as above with a gradient on the depth output too (the DEPTH instantiation of the blending backward), on the
+    generator's (random) order of the Gaussians: the plane-gradient kernel's fallback path at full size."""
+    test_render_fwd_bwd_parity_at_baseline_size("cfg4_dynerf_300k_1352x1014", True, order="random")
+
+
+def test_spatial_reorder_leaves_the_frame_unchanged_and_permutes_the_gradients():
+    """Hilbert-ordering the model (what the train loop does after every densification) is semantically free: same image to
+    1e-6, same radii and per-Gaussian gradients up to the permutation, same plane / MLP gradients."""
+    fd = importlib.import_module("4dgaussians_amd")
+    dev = torch.device("cuda:0")
+    N, W, H = 60_000, 640, 480
+    cam = synthetic.orbit_cameras(W, H, n=160)[21].to(dev)
+    wimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
+    outs = []
+    for reorder in (False, True):
+        pc = synthetic.SynthModel(N, "dynerf_default", seed=77).to(dev)
+        with torch.no_grad():
+            pc._scaling.add_(0.5)
+        perm = fd.densify.spatial_reorder(pc) if reorder else torch.arange(N, device=dev)
+        res = fd.render(cam, pc, synthetic.PipelineParams(), torch.zeros(3, device=dev), stage="fine")
+        (res["render"] * wimg).sum().backward()
+        outs.append((res, {k: v.grad for k, v in pc.named_parameters() if v.grad is not None}, perm))
+    (ra, ga, _), (rb, gb, perm) = outs
+    d = (ra["render"] - rb["render"]).abs()
+    print(f"image max diff {float(d.max()):.2e}, mean {float(d.mean()):.2e}")
+    assert float(d.mean()) < 1e-7 and float(torch.quantile(d.flatten()[::7], 0.9999)) < 1e-5     # (equal-depth ties may reorder)
+    assert torch.equal(ra["radii"][perm], rb["radii"])
+    for k in ga:
+        a, b = ga[k], gb[k]
+        if k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+            a = a[perm]
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-4, k
