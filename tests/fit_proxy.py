@@ -1,0 +1,133 @@
+"""End-to-end quality proxy for north_star's "PSNR within 0.05 dB of reference" (the datasets and the reference's CUDA
+rasterizer are not available): a small synthetic FIT -- the reference's fine-stage optimisation loop (train.py:180-292: per
+iteration one view, render, L1 loss against the ground-truth image, backward, Adam step over the eight parameter groups
+with the reference's learning rates; densification off) -- run twice from identical initial parameters, identical camera
+order and identical targets:
+
+  * through the product path: fdgs.render() (HIP) + fdgs.losses.l1_loss + fdgs.FusedAdam on the GPU;
+  * through the oracle chain on the CPU: deformation oracle (pinned to the reference modules) -> C rasterizer restatement
+    (forward + analytic backward) -> torch-CPU autograd -> torch.optim.Adam (what the reference itself steps with).
+
+Targets are frames of a perturbed "ground-truth" copy of the model rendered by the ORACLE.  The two PSNR curves and the final
+PSNR over all training views are compared.  This file is test infrastructure (it imports oracle/)."""
+import importlib
+import math
+
+import numpy as np
+import torch
+
+from oracle import deform_oracle as DO
+from oracle.raster_oracle import RasterOracle
+
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+LRS = {"xyz": 0.00016, "deformation": 0.00016, "grid": 0.0016, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.05, "scaling": 0.005,
+       "rotation": 0.001}       # arguments/__init__.py:116-129 (xyz / deformation / grid: initial values; spatial_lr_scale 1)
+
+
+def _oracle_frame(sd, flags, leaves, cam, want_grad, target=None):
+    """One frame through the oracle chain.  Returns (image [3,H,W] float32, l1, psnr) and, with want_grad, leaves .grad filled."""
+    n = leaves["_xyz"].shape[0]
+    shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
+    with torch.set_grad_enabled(want_grad):
+        outs = DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
+                                 torch.full((n, 1), cam.time), activate=True)
+    f = lambda x: np.ascontiguousarray(x.detach().numpy())
+    H, W = cam.image_height, cam.image_width
+    o = RasterOracle(means3D=f(outs[0]), scales=f(outs[1]), rotations=f(outs[2]), opacities=f(outs[3]), shs=f(outs[4]),
+                     viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
+                     bg=np.zeros(3, np.float32), image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5),
+                     tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+    img = o.color.copy()
+    l1 = psnr = None
+    if target is not None:
+        d = img - target
+        l1 = float(np.abs(d).mean())
+        psnr = 10 * math.log10(1.0 / max(float((d.astype(np.float64) ** 2).mean()), 1e-20))
+    if want_grad:
+        dc = (np.sign(img - target) / img.size).astype(np.float32)          # d mean|img - target| / d img
+        g = o.backward(dc)
+        gouts = [torch.tensor(g["means3D"]), torch.tensor(g["scales"]), torch.tensor(g["rotations"]),
+                 torch.tensor(g["opacities"]).reshape(outs[3].shape), torch.tensor(g["shs"]).reshape(outs[4].shape)]
+        torch.autograd.backward(list(outs), gouts)
+    o.close()
+    return img, l1, psnr
+
+
+def make_problem(n=1500, W=96, H=72, cfg="dynerf_default", views=6, seed=4):
+    """Initial (student) model, ground-truth images, cameras.  Small planes keep the CPU leg fast."""
+    res = {"resolution": [16, 16, 16, 10]}
+    kp = dict(synthetic.DEFORM_CONFIGS[cfg]["kplanes_config"]); kp.update(res)
+    import types
+    old = synthetic.DEFORM_CONFIGS[cfg]["kplanes_config"]
+    synthetic.DEFORM_CONFIGS[cfg]["kplanes_config"] = kp
+    try:
+        student = synthetic.SynthModel(n, cfg, seed=seed)
+    finally:
+        synthetic.DEFORM_CONFIGS[cfg]["kplanes_config"] = old
+    with torch.no_grad():
+        student._scaling.add_(1.2)                     # splats large enough to cover the small image
+    cams = [synthetic.make_camera(W, H, theta_deg=-150.0 + 55.0 * i, time=i / max(views - 1, 1)) for i in range(views)]
+    # ground truth = the student's parameters moved by a seeded perturbation
+    gen = torch.Generator().manual_seed(seed + 100)
+    sd_gt = {k: v.detach().clone() for k, v in student._deformation.state_dict().items()}
+    for k, v in sd_gt.items():
+        if "grids" in k:
+            v.add_(0.05 * torch.randn(v.shape, generator=gen))
+    leaves_gt = {k: getattr(student, k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    leaves_gt["_xyz"] += 0.02 * torch.randn(leaves_gt["_xyz"].shape, generator=gen)
+    leaves_gt["_features_dc"] += 0.5 * torch.randn(leaves_gt["_features_dc"].shape, generator=gen)
+    leaves_gt["_opacity"] += 0.5 * torch.randn(leaves_gt["_opacity"].shape, generator=gen)
+    leaves_gt["_scaling"] += 0.1 * torch.randn(leaves_gt["_scaling"].shape, generator=gen)
+    targets = [_oracle_frame(sd_gt, student._deformation.args, leaves_gt, c, False)[0] for c in cams]
+    return student, cams, targets
+
+
+def run_oracle(student, cams, targets, iters):
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in student._deformation.state_dict().items()}
+    leaves = {k: getattr(student, k).detach().clone().requires_grad_(True)
+              for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    mlp = [v for k, v in sd.items() if v.requires_grad and "grids" not in k]
+    grid = [v for k, v in sd.items() if v.requires_grad and "grids" in k]
+    groups = [{"params": [leaves["_xyz"]], "lr": LRS["xyz"]}, {"params": mlp, "lr": LRS["deformation"]}, {"params": grid, "lr": LRS["grid"]},
+              {"params": [leaves["_features_dc"]], "lr": LRS["f_dc"]}, {"params": [leaves["_features_rest"]], "lr": LRS["f_rest"]},
+              {"params": [leaves["_opacity"]], "lr": LRS["opacity"]}, {"params": [leaves["_scaling"]], "lr": LRS["scaling"]},
+              {"params": [leaves["_rotation"]], "lr": LRS["rotation"]}]
+    opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)              # scene/gaussian_model.py:184
+    curve = []
+    for it in range(iters):
+        v = it % len(cams)
+        opt.zero_grad(set_to_none=True)
+        _, l1, ps = _oracle_frame(sd, student._deformation.args, leaves, cams[v], True, targets[v])
+        curve.append(ps)
+        opt.step()
+    final = [_oracle_frame(sd, student._deformation.args, leaves, c, False, t)[2] for c, t in zip(cams, targets)]
+    return curve, final
+
+
+def run_hip(student, cams, targets, iters, device="cuda:0"):
+    import copy
+    fdgs = importlib.import_module("4dgaussians_amd")
+    dev = torch.device(device)
+    pc = copy.deepcopy(student).to(dev)
+    groups = pc.optimizer_groups()
+    for g in groups:
+        g["lr"] = LRS[g["name"]]
+    opt = fdgs.FusedAdam(groups, lr=0.0, eps=1e-15)
+    tg = [torch.tensor(t, device=dev) for t in targets]
+    cg = [c.to(dev) for c in cams]
+    pipe, bg = synthetic.PipelineParams(), torch.zeros(3, device=dev)
+    curve = []
+    for it in range(iters):
+        v = it % len(cams)
+        opt.zero_grad(set_to_none=True)
+        img = fdgs.render(cg[v], pc, pipe, bg, stage="fine")["render"]
+        loss = fdgs.losses.l1_loss(img, tg[v])
+        loss.backward()
+        with torch.no_grad():
+            curve.append(float(fdgs.losses.psnr(img, tg[v]).mean()))
+        opt.step()
+    with torch.no_grad():
+        final = [float(fdgs.losses.psnr(fdgs.render(c, pc, pipe, bg, stage="fine")["render"], t).mean()) for c, t in zip(cg, tg)]
+    return curve, final

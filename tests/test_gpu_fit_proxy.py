@@ -1,0 +1,31 @@
+"""Quality proxy of the end-to-end target (see tests/fit_proxy.py): the same 300-iteration fit through the HIP path and through
+the CPU oracle chain ends at the same PSNR to within north_star's 0.05 dB."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fit_proxy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fit_through_hip_path_matches_fit_through_oracle_chain():
+    iters = 300
+    student, cams, targets = fit_proxy.make_problem()
+    c_ref, f_ref = fit_proxy.run_oracle(student, cams, targets, iters)
+    c_hip, f_hip = fit_proxy.run_hip(student, cams, targets, iters)
+    m_ref, m_hip = float(np.mean(f_ref)), float(np.mean(f_hip))
+    head = float(np.mean(c_ref[:6]))
+    print(f"PSNR over the {len(cams)} training views: start {head:.2f} dB -> oracle chain {m_ref:.3f} dB, HIP path {m_hip:.3f} dB (diff {m_hip - m_ref:+.4f} dB)")
+    print("   per view (oracle / HIP): " + ", ".join(f"{a:.2f}/{b:.2f}" for a, b in zip(f_ref, f_hip)))
+    drift = np.abs(np.array(c_ref) - np.array(c_hip))
+    print(f"   curve drift |PSNR_hip - PSNR_oracle| per iteration: first 50 max {drift[:50].max():.4f}, overall max {drift.max():.4f} dB")
+    out = os.environ.get("FDGS_FIT_PROXY_JSON")
+    if out:
+        json.dump({"iterations": iters, "views": len(cams), "psnr_start_dB": head, "final_psnr_oracle_dB": m_ref, "final_psnr_hip_dB": m_hip,
+                   "final_per_view_oracle": f_ref, "final_per_view_hip": f_hip, "curve_oracle": c_ref, "curve_hip": c_hip}, open(out, "w"))
+    assert m_ref > head + 3.0, "the fit must actually improve the images for the comparison to mean anything"
+    assert abs(m_hip - m_ref) < 0.05
+    assert drift[:20].max() < 0.01            # identical start: the first iterations agree to rounding
