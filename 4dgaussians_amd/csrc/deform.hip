@@ -1591,7 +1591,6 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
 //             them to the workgroup's private LDS row with plain read-add-writes (one owner wave: no LDS float atomics,
 //             which run at 0.33 lanes/clk/CU), flushed once per workgroup with the two time weights.
 // Every path adds the same products; only the summation order differs from the per-corner atomics.
-constexpr int PGM_THREADS = 512;     // 8 waves, 256 VGPRs each: one workgroup per CU (LDS), the sampling pass needs ~150 registers
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -1611,14 +1610,22 @@ __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int C>
-__global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(PlaneGradMArgs ma) {
+// NWV = 8: one 512-thread workgroup per CU, 2048 / C Gaussians per chunk, two waves per spatial plane (halves of the window rows),
+//          the window flush deferred by one phase (see `acc`).
+// NWV = 4: 256-thread workgroups with half the chunk, TWO per CU when the LDS allows (one's sampling phase overlaps the other's
+//          matrix-core phase, which a single workgroup can only do by idling six of its waves at the barrier); one wave per plane,
+//          windows flushed at once (the other workgroup covers the wait).
+template <int C, int NWV>
+__global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_mfma_kernel(PlaneGradMArgs ma) {
+    constexpr int PGM_T = 64 * NWV;
     const PlaneGradArgs& a = ma.g;
     const fdgs_deform_params& p = a.p;
     extern __shared__ float4 pgm_lds4[];
     float* lds = reinterpret_cast<float*>(pgm_lds4);
-    constexpr int G = 2048 / C;                       // Gaussians per chunk = per sampling pass of the workgroup
-    constexpr int NW = PGM_THREADS / 64;
+    constexpr int G = (NWV == 8 ? 2048 : 1024) / C;   // Gaussians per chunk
+    constexpr int NW = NWV;
+    constexpr bool DEFER = NWV == 8;
+    constexpr int LISTS = NWV == 8 ? 8 : 15, NACC = LISTS + 1;   // row lists per spatial wave / window rows it accumulates
     constexpr int CG = C / 4, LPG = 2 * CG, GPW = 64 / LPG;   // sampling pass: lane = (Gaussian, x-corner, group of 4 channels)
     constexpr int NB = G / (GPW * NW);                        // sampling passes per chunk
     static_assert(NB * GPW * NW == G, "whole sampling passes");
@@ -1640,11 +1647,11 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
     // window of the previous phase, kept in registers: its atomics are issued at the START of the next matrix-core loop and drain
     // while that loop runs (loads, stores and no-return atomics share one in-order counter: a sampling load issued right after a
     // flush could only be waited for together with the whole flush)
-    f32x4v acc[9];
+    f32x4v acc[NACC];
     uint32_t pend_rows = 0;
     float* pend_dP = nullptr;
     int pend_ox = 0, pend_oy = 0, pend_Wd = 0, pend_Hd = 0, pend_hf = 0;
-    for (int i = tid; i < a.lds_floats; i += PGM_THREADS) lds[i] = 0.f;     // private time rows
+    for (int i = tid; i < a.lds_floats; i += PGM_T) lds[i] = 0.f;     // private time rows
 #ifdef FDGS_PROFILE_D4
     unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
@@ -1657,7 +1664,7 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
         const int n0 = chunk * G;
         // ---- S0: coordinates -> LDS, per-axis minimum over the chunk (the texel index is monotonic in the coordinate, so the
         // window origin of every level follows from the three minima)
-        if (tid >= PGM_THREADS - 40) s_cnt_all[tid - (PGM_THREADS - 40)] = 0;
+        if (tid >= PGM_T - 40) s_cnt_all[tid - (PGM_T - 40)] = 0;
         if (tid < G) {
             const int n = n0 + tid;
             const bool live = n < p.N;
@@ -1790,8 +1797,8 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
             if (wave == NW - 1 && lane < 40) s_cnt_all[((lvl + 1) & 1) * 40 + lane] = 0;
             // ---- M: waves 0..5 = (spatial plane, half of the window rows), waves 6, 7 = time planes
             const int gk = lane >> 4, il = lane & 15;         // Gaussian of the k-step / texel of the tile (A), channel (B)
-            if (wave < 6) {
-                const int pi = wave >> 1, hh = wave & 1;
+            if (wave < (NWV == 8 ? 6 : 3)) {
+                const int pi = NWV == 8 ? wave >> 1 : wave, hh = NWV == 8 ? (wave & 1) : 0;
                 const int k = pi == 2 ? 3 : pi;
                 float* dP = a.d_planes[lvl][k];
                 if (dP) {
@@ -1806,7 +1813,7 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
                         // row 8 hh + rr, channel il
                         if (pend_rows) {
 #pragma unroll
-                            for (int rr = 0; rr < 9; rr++) {
+                            for (int rr = 0; rr < NACC; rr++) {
                                 if ((pend_rows >> rr) & 1u) {
                                     const int y = pend_oy + rr;
 #pragma unroll
@@ -1820,11 +1827,11 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
                         }
                         D4_TICK(4);
 #pragma unroll
-                        for (int r = 0; r < 9; r++) acc[r] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                        for (int r = 0; r < NACC; r++) acc[r] = f32x4v{0.f, 0.f, 0.f, 0.f};
                         uint32_t rows_any = 0;
 #pragma unroll
-                        for (int rr = 0; rr < 8; rr++) {
-                            const int r = 8 * hh + rr;                 // list of window row r feeds rows r and r + 1 (r <= 14)
+                        for (int rr = 0; rr < LISTS; rr++) {
+                            const int r = LISTS * hh + rr;             // list of window row r feeds rows r and r + 1 (r <= 14)
                             const int nr = r <= 14 ? s_cnt[bin * 16 + r] : 0;
                             const uint8_t* lst = s_list + (bin * 16 + r) * G;
                             // two steps (8 Gaussians) per iteration; the list bytes of the next iteration are requested before this
@@ -1852,13 +1859,28 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
                             }
                             if (nr > 0) rows_any |= 3u << rr;
                         }
-                        pend_rows = rows_any; pend_dP = dP; pend_ox = ox; pend_oy = oy + 8 * hh; pend_Wd = p.res[lvl][ax]; pend_Hd = p.res[lvl][bx];
+                        pend_rows = rows_any; pend_dP = dP; pend_ox = ox; pend_oy = oy + LISTS * hh; pend_Wd = p.res[lvl][ax]; pend_Hd = p.res[lvl][bx];
                         pend_hf = hf;
                         D4_TICK(3);
+                        if (!DEFER && pend_rows) {
+#pragma unroll
+                            for (int rr = 0; rr < NACC; rr++) {
+                                if ((pend_rows >> rr) & 1u) {
+                                    const int y = pend_oy + rr;
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        const int x = pend_ox + 4 * gk + j;
+                                        const float v = acc[rr][j];
+                                        if (v != 0.f && x < pend_Wd && y < pend_Hd) atomicAdd(&pend_dP[((size_t)y * pend_Wd + x) * C + pend_hf * 16 + il], v);
+                                    }
+                                }
+                            }
+                            pend_rows = 0;
+                        }
                     }
                 }
-            } else {
-                for (int slot = wave == 6 ? 0 : 2; slot < (wave == 6 ? 2 : 3); slot++) {
+            } else if (NWV == 8 || wave == 3) {
+                for (int slot = NWV == 4 ? 0 : (wave == 6 ? 0 : 2); slot < (NWV == 4 ? 3 : (wave == 6 ? 2 : 3)); slot++) {
                     const int k = slot == 0 ? 2 : (slot == 1 ? 4 : 5);
                     const int loff = slot == 0 ? lo0 : (slot == 1 ? lo1 : lo2);
                     if (loff < 0) continue;
@@ -1977,10 +1999,10 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
         __syncthreads();
         D4_TICK(7);
     }
-    if (wave < 6 && pend_rows) {          // the last window of this wave
+    if (pend_rows) {          // the last window of this wave (deferred flush)
         const int gk = lane >> 4, il = lane & 15;
 #pragma unroll
-        for (int rr = 0; rr < 9; rr++) {
+        for (int rr = 0; rr < NACC; rr++) {
             if ((pend_rows >> rr) & 1u) {
                 const int y = pend_oy + rr;
 #pragma unroll
@@ -1994,7 +2016,7 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
     }
 #ifdef FDGS_PROFILE_D4
     if (ma.prof && lane == 0 && blockIdx.x < 64) {
-        unsigned long long* out = ma.prof + (size_t)(blockIdx.x * NW + wave) * 10;
+        unsigned long long* out = ma.prof + (size_t)(blockIdx.x * 8 + wave) * 10;
         for (int i = 0; i < 8; i++) out[i] = prof_acc[i];
         out[9] = __builtin_amdgcn_s_memtime() - prof_t0;
     }
@@ -2012,7 +2034,7 @@ __global__ void __launch_bounds__(PGM_THREADS) deform_plane_grad_mfma_kernel(Pla
             float* dP = a.d_planes[lvl][k];
             float* r0 = dP + (size_t)st.i0 * Wd * C;
             float* r1 = dP + (size_t)st.i1 * Wd * C;
-            for (int i = tid; i < Wd * C; i += PGM_THREADS) {
+            for (int i = tid; i < Wd * C; i += PGM_T) {
                 const float v = lds[loff + i];
                 if (v != 0.f) {
                     atomicAdd(&r0[i], v * st.w0);
@@ -2332,8 +2354,13 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         // matrix-core splat (default whenever one frame time is shared by all Gaussians, i.e. on the render() path): the
         // fixed LDS part is the dv tile, coordinates, descriptors; the time rows get what is left of the 160 KB
         const bool use_mfma = !p->time && tunable("FDGS_D4_MFMA", 1);
-        const int Gc = 2048 / p->C;
-        const int fixed_floats = 6 * 2048 + 3 * Gc + 13 * Gc + 3 * Gc + (96 + 9 * Gc) + 64;
+        // workgroup shape of the splat: 8 waves, one workgroup per CU (default); FDGS_D4_WAVES=4 selects 4-wave workgroups with half
+        // the chunk, two per CU where the LDS allows -- measured equal on BASELINE config 4 (0.331 vs 0.322 ms: overlapping one
+        // workgroup's sampling with the other's matrix-core phase buys what the smaller chunks lose in merging), kept for A/B
+        auto fixed_floats_of = [&](int nwv) { const int Gv = (nwv == 8 ? 2048 : 1024) / p->C; return 6 * Gv * p->C + 3 * Gv + 13 * Gv + 3 * Gv + (96 + 9 * Gv) + 64; };
+        const int nwv = tunable("FDGS_D4_WAVES", 8) == 4 ? 4 : 8;
+        const int Gc = (nwv == 8 ? 2048 : 1024) / p->C;
+        const int fixed_floats = fixed_floats_of(nwv);
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
         // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
         // atomics on ~128 hot lines, is 4x slower than scattered atomics)
@@ -2367,24 +2394,31 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
 #endif
             ma.nchunks = cdiv(p->N, Gc);
             int o = (used + 63) / 64 * 64;
-            ma.off_dv = o; o += 6 * 2048;
+            ma.off_dv = o; o += 6 * Gc * p->C;
             ma.off_q = o; o += 3 * Gc;
             ma.off_desc = o; o += 13 * Gc;   // [3][G] float4 axis descriptors + [G] window masks
             ma.off_dq = o; o += 3 * Gc;
-            ma.off_org = o; o += 96 + 9 * Gc;   // per-wave minima, row counters, row lists
+            ma.off_org = o; o += 96 + 9 * Gc;
             const size_t lds_bytes = (size_t)o * 4;
-            int blocks = tunable("FDGS_PGM_WGS", 256);
+            int blocks = tunable("FDGS_PGM_WGS", nwv == 4 ? 512 : 256);
             if (blocks > ma.nchunks) blocks = ma.nchunks;
-            static bool raised16 = false, raised32 = false;
-            bool& raised = p->C == 16 ? raised16 : raised32;
-            if (!raised) {
-                const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16>)
-                                            : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32>);
+            const void* fn = p->C == 16 ? (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 4>)
+                                                     : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 8>))
+                                        : (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 4>)
+                                                     : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 8>));
+            static bool raised[4] = {false, false, false, false};
+            bool& r_ = raised[(p->C == 16 ? 0 : 2) + (nwv == 4 ? 0 : 1)];
+            if (!r_) {
                 FDGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
+                r_ = true;
             }
-            if (p->C == 16) { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16>), dim3(blocks), dim3(PGM_THREADS), lds_bytes, stream, ma); }
-            else { FDGS_TIMED("deform_plane_grad", stream); hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32>), dim3(blocks), dim3(PGM_THREADS), lds_bytes, stream, ma); }
+            {
+                FDGS_TIMED("deform_plane_grad", stream);
+                if (p->C == 16 && nwv == 4) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16, 4>), dim3(blocks), dim3(256), lds_bytes, stream, ma);
+                else if (p->C == 16) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16, 8>), dim3(blocks), dim3(512), lds_bytes, stream, ma);
+                else if (nwv == 4) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32, 4>), dim3(blocks), dim3(256), lds_bytes, stream, ma);
+                else hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32, 8>), dim3(blocks), dim3(512), lds_bytes, stream, ma);
+            }
             FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
 #ifdef FDGS_PROFILE_D4
             {
@@ -2394,7 +2428,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
                     (void)hipStreamSynchronize(stream);
                     (void)hipMemcpy(hbuf.data(), prof_dev, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                     const char* nm[8] = {"S0+bar", "S", "bar(S)", "M.sp.loop", "M.sp.flush", "M.time", "bar(M)", "dxyz+bar"};
-                    for (int wv : {0, 1, 2, 5, 6, 7}) {
+                    for (int wv : {0, 1, 2, 3, 5, 6, 7}) {
                         double sum[10] = {0}; int cnt = 0;
                         for (int b = 0; b < 64; b++) { const unsigned long long* r = &hbuf[(size_t)(b * 8 + wv) * 10]; if (!r[9]) continue; cnt++; for (int i = 0; i < 10; i++) sum[i] += (double)r[i]; }
                         if (!cnt) continue;

@@ -28,4 +28,5 @@ def test_fit_through_hip_path_matches_fit_through_oracle_chain():
                    "final_per_view_oracle": f_ref, "final_per_view_hip": f_hip, "curve_oracle": c_ref, "curve_hip": c_hip}, open(out, "w"))
     assert m_ref > head + 3.0, "the fit must actually improve the images for the comparison to mean anything"
     assert abs(m_hip - m_ref) < 0.05
-    assert drift[:20].max() < 0.01            # identical start: the first iterations agree to rounding
+    assert max(abs(a - b) for a, b in zip(f_ref, f_hip)) < 0.1      # every single view, too
+    assert drift[:40].max() < 0.01            # identical start: the first iterations agree to rounding
