@@ -257,7 +257,7 @@ def run(args):
         out = {
             "metric": "train-step frames/sec (fwd+bwd raster+deform)", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "lib_sha16": lib_sha16(fdgs),
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "src_sha16": lib_sha16(fdgs),
             "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "gaussian_order": args.order, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "train_iteration": train,
@@ -277,15 +277,22 @@ def run(args):
 
 
 def lib_sha16(fdgs):
+    """Hash of the kernel sources libfdgs.so is built from (the same value tools/pmc_traffic.py stamps on a counter artefact)."""
+    import glob
     import hashlib
-    return hashlib.sha256(open(fdgs._lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "4dgaussians_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "fdgs.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel, workload, lib_sha):
     """HBM-side bytes per launch of `kernel` from a committed rocprofv3 PMC artefact (profiles/*_pmc_traffic*.json, written by
     tools/pmc_traffic.py from separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over this same bench command).  An
-    artefact is only used when it was collected for THIS workload with THIS build of libfdgs.so (`_workload`, `_lib_sha16`
-    keys): anything else gives traffic = null plus the reason -- a counter from another workload or build is not a
+    artefact is only used when it was collected for THIS workload with THIS build of libfdgs.so (`_workload`, `_src_sha16`
+    keys: a hash of the kernel sources): anything else gives traffic = null plus the reason -- a counter from another workload or build is not a
     measurement of this run.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KB; on
     gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads (what these kernels issue), so it is
     doubled; WRITE_SIZE is uncalibrated there and taken as reported."""
@@ -297,8 +304,8 @@ def pmc_traffic(kernel, workload, lib_sha):
         if d.get("_workload") != workload:
             reasons.append(f"{os.path.basename(f)}: workload {d.get('_workload')!r}")
             continue
-        if d.get("_lib_sha16") != lib_sha:
-            reasons.append(f"{os.path.basename(f)}: other build ({d.get('_lib_sha16')})")
+        if d.get("_src_sha16") != lib_sha:
+            reasons.append(f"{os.path.basename(f)}: other build ({d.get('_src_sha16')})")
             continue
         k = d.get(kernel)
         if not k:
@@ -308,7 +315,7 @@ def pmc_traffic(kernel, workload, lib_sha):
                 "traffic_detail": {"FETCH_SIZE_bytes_raw": fetch, "FETCH_SIZE_bytes_corrected_x2": 2 * fetch, "WRITE_SIZE_bytes": write},
                 "traffic_source": "profiles/" + os.path.basename(f)}
     return {"traffic": None, "traffic_source": None,
-            "traffic_refused": ("no PMC artefact for this workload and build (libfdgs sha16 " + lib_sha + "); not used: " + "; ".join(reasons[:4]))
+            "traffic_refused": ("no PMC artefact for this workload and build (kernel sources sha16 " + lib_sha + "); not used: " + "; ".join(reasons[:4]))
             if reasons else "no PMC artefact under profiles/"}
 
 

@@ -36,7 +36,7 @@ pmc_one() {  # $1 = workload, $2 = suffix: FETCH_SIZE and WRITE_SIZE in separate
     timeout 240 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_pmc_${C}$2 -o pmc --output-format csv -- python $R/bench.py --workload $1 --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1
   done
   cd $R
-  ST=$(ls gpurun_out/${TAG}_prof$2/*/*kernel_stats.csv 2>/dev/null | head -1)
+  ST=gpurun_out/${TAG}_kernel_stats$2.txt
   python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_FETCH_SIZE$2 gpurun_out/${TAG}_pmc_WRITE_SIZE$2 $1 gpurun_out/${TAG}_pmc_traffic$2.json $ST
 }
 WL0=cfg4_dynerf_300k_1352x1014

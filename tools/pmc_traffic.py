@@ -15,7 +15,19 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALIAS = {"radix_digit_scan": "radix_scan", "scan_chunk": "scan_tiles", "scan_add": "scan_tiles", "adam": "adam_step"}
+ALIAS = {"radix_digit_scan": "radix_scan", "scan_chunk": "scan_tiles", "scan_add": "scan_tiles", "adam": "adam_step",
+         "deform_plane_grad_mfma": "deform_plane_grad"}
+
+
+def src_sha16():
+    """Hash of every kernel source the library is built from: the key that ties a counter artefact to a build (a hash of the
+    binary would change with the build path; bench.py computes the same value)."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "4dgaussians_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "fdgs.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -40,19 +52,33 @@ def per_launch(d, counter):
 def main():
     fetch_dir, write_dir, workload, out = sys.argv[1:5]
     stats = sys.argv[5] if len(sys.argv) > 5 else None
-    fe, wr = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
-    lib = os.path.join(ROOT, "4dgaussians_amd", "libfdgs.so")
-    res = {"_workload": workload, "_lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+    if fetch_dir == "--merge":      # add durations to an existing artefact: pmc_traffic.py --merge IN.json WORKLOAD OUT.json STATS
+        old = json.load(open(write_dir))
+        fe = {k: (v["FETCH_SIZE_KB_per_launch"], v.get("launches_profiled", 0)) for k, v in old.items() if not k.startswith("_")}
+        wr = {k: (v["WRITE_SIZE_KB_per_launch"], v.get("launches_profiled", 0)) for k, v in old.items() if not k.startswith("_")}
+        fe = {ALIAS.get(k, k): v for k, v in fe.items()}
+        wr = {ALIAS.get(k, k): v for k, v in wr.items()}
+    else:
+        fe, wr = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
+    res = {"_workload": workload, "_src_sha16": src_sha16(),
            "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --workload "
                       + workload + " --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-train-step, MI355X",
            "_units": "KB per launch as reported by rocprofv3 (TCC_EA0 request counters x 64 B); gfx950 reports HALF of the bytes of "
                      "16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section): consumers double FETCH_SIZE"}
     dur = {}
-    if stats and os.path.exists(stats):
+    if stats and os.path.exists(stats) and stats.endswith(".csv"):
         for r in csv.DictReader(open(stats)):
             k = short(r["Name"])
             c, t = dur.get(k, (0, 0.0))
             dur[k] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
+    elif stats and os.path.exists(stats):          # the text summary tools/gpu_round.sh writes (kernel, calls, total_ms, avg_us, pct)
+        for line in open(stats).read().splitlines()[1:]:
+            name, rest = line[:60], line[60:].split()
+            if len(rest) < 3:
+                continue
+            k = short(name.strip())
+            c, t = dur.get(k, (0, 0.0))
+            dur[k] = (c + int(rest[0]), t + float(rest[1]) * 1e6)
     frame_bytes = frame_ns = 0.0
     for k in sorted(set(fe) | set(wr)):
         f, nf = fe.get(k, (0.0, 0))
