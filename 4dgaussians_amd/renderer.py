@@ -22,12 +22,10 @@ def _dev(t, device):
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, stage="fine", cam_type=None):
     means3D = pc.get_xyz
     device = means3D.device
-    # gradient sink for the screen-space means (train.py:223-225 reads .grad of this tensor)
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # gradient sink for the screen-space means (train.py:223-225 reads .grad of this tensor).  A LEAF of zeros: the reference's
+    # `zeros_like(...) + 0` with retain_grad() costs an extra add kernel per frame plus a clone of the gradient in the retain hook;
+    # a leaf's .grad is filled by AccumulateGrad directly (same values, same attribute, read the same way by the train loop)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device)
     if cam_type != "PanopticSports":
         tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
         tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
