@@ -20,10 +20,17 @@ class RasterParams(Structure):
                 ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p)]
 
 
+class RasterDeformEpilogue(Structure):
+    _fields_ = [("activate", c_int), ("Npad", c_int), ("rot_norm", c_void_p), ("G", c_void_p), ("d_xyz", c_void_p),
+                ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p), ("d_shs_dc", c_void_p),
+                ("d_shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int), ("assign", c_int)]
+
+
 class RasterGrads(Structure):
     _fields_ = [("dL_dcolor", c_void_p), ("dL_ddepth", c_void_p), ("dL_dmeans2D", c_void_p), ("dL_dmeans3D", c_void_p),
                 ("dL_dopacity", c_void_p), ("dL_dcolors", c_void_p), ("dL_dsh", c_void_p), ("dL_dscales", c_void_p),
-                ("dL_drotations", c_void_p), ("dL_dcov3D", c_void_p), ("scratch_acc", c_void_p)]
+                ("dL_drotations", c_void_p), ("dL_dcov3D", c_void_p), ("scratch_acc", c_void_p),
+                ("deform_epilogue", POINTER(RasterDeformEpilogue))]
 
 
 class DeformParams(Structure):
@@ -47,7 +54,8 @@ class DeformGrads(Structure):
                 ("rot_norm", c_void_p), ("d_xyz", c_void_p), ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p),
                 ("d_shs_dc", c_void_p), ("d_shs_rest", c_void_p), ("d_planes", (c_void_p * 6) * MAX_LEVELS),
                 ("d_w0", c_void_p), ("d_b0", c_void_p), ("d_w1", c_void_p * NUM_HEADS), ("d_b1", c_void_p * NUM_HEADS),
-                ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p), ("saved", c_void_p)]
+                ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p), ("saved", c_void_p),
+                ("packed_rows_ready", c_int)]
 
 
 class RegPlane(Structure):

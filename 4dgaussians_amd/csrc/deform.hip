@@ -2213,7 +2213,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     if (rc) return rc;
     FDGS_REQUIRE(g && g->scratch, "grads/scratch is NULL");
     if (p->N == 0) return FDGS_OK;
-    if (p->activate) {
+    if (p->activate && !g->packed_rows_ready) {
         FDGS_REQUIRE(!g->g_scales || g->out_scales, "out_scales needed with activate=1");
         FDGS_REQUIRE(!g->g_rotations || (g->out_rotations && g->rot_norm), "out_rotations/rot_norm needed with activate=1");
         FDGS_REQUIRE(!g->g_opacity || g->out_opacity, "out_opacity needed with activate=1");
@@ -2237,8 +2237,10 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     pa.out_scales = g->out_scales; pa.out_rot = g->out_rotations; pa.out_opacity = g->out_opacity; pa.rot_norm = g->rot_norm;
     pa.d_xyz = g->d_xyz; pa.d_scales = g->d_scales; pa.d_rot = g->d_rotations; pa.d_opacity = g->d_opacity;
     pa.d_shs_dc = g->d_shs_dc; pa.d_shs_rest = g->d_shs_rest; pa.G = s.G;
-    { FDGS_TIMED("deform_bwd_prep", stream); hipLaunchKernelGGL(deform_bwd_prep_kernel, dim3(cdiv((long long)Np, 256)), dim3(256), 0, stream, pa); }
-    FDGS_LAUNCH_CHECK("deform_bwd_prep", 0, stream);
+    if (!g->packed_rows_ready) {    // (1: fdgs_raster_bwd's deformation epilogue already wrote G and the identity paths)
+        { FDGS_TIMED("deform_bwd_prep", stream); hipLaunchKernelGGL(deform_bwd_prep_kernel, dim3(cdiv((long long)Np, 256)), dim3(256), 0, stream, pa); }
+        FDGS_LAUNCH_CHECK("deform_bwd_prep", 0, stream);
+    }
     if (nh == 0) return FDGS_OK;  // no head active: the deformation is the identity
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++)
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");

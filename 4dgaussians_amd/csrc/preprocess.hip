@@ -140,6 +140,9 @@ struct PreBwdArgs {
     const float* gacc;           // [P,16] packed sums written by render_bwd (layout in render.hip)
     float *dL_dmeans2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dsh, *dL_dscales, *dL_drot, *dL_dcov3D;
+    // EPI: the deformation epilogue (fdgs_raster_deform_epilogue) + the activated opacities the rasterizer received
+    fdgs_raster_deform_epilogue epi;
+    const float* opacities;
 };
 
 // Block-linear store of K floats per Gaussian for the 64 Gaussians of a wave: lanes park their K values in LDS as
@@ -174,14 +177,18 @@ __device__ __forceinline__ void wave_store_rows(float* __restrict__ out_block, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// EPI: instead of dL_dmeans3D / dL_dscales / dL_drot / dL_dopacity / dL_dsh the kernel writes what fdgs_deform_bwd consumes: the packed
+// pre-activation gradient rows G[Npad][64] (activation Jacobians applied) and the identity paths, block-linear like everything else
+// (this is deform_bwd_prep_kernel's job done where the values are still in registers: one kernel and 2 x 236 B per Gaussian less).
+template <bool EPI>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * 48];
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * (EPI ? 64 : 48)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* buf = lds_all + wave * 64 * 48;
+    float* buf = lds_all + wave * 64 * (EPI ? 64 : 48);
     const int n0 = (blockIdx.x * 4 + wave) * 64;
-    if (n0 >= a.P) return;
+    if (n0 >= (EPI ? a.epi.Npad : a.P)) return;
     const int i = n0 + lane;
-    const int nvalid = a.P - n0 < 64 ? a.P - n0 : 64;
+    const int nvalid = a.P - n0 < 64 ? (a.P - n0 > 0 ? a.P - n0 : 0) : 64;
     const bool active = i < a.P && a.tiles[i] != 0;
     // every output row is written (zeros for culled / zero-area Gaussians): the caller needs no memsets
     float m2d[3] = {0.f, 0.f, 0.f}, dop = 0.f, drgb[3] = {0.f, 0.f, 0.f}, dcov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -214,6 +221,112 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
             float q[4] = {qv.x, qv.y, qv.z, qv.w};
             cov3d_bwd(s, c.scale_mod, q, dcov6, ds, dq);
         }
+    }
+    if constexpr (EPI) {
+        wave_store_rows<3>(a.dL_dmeans2D + (size_t)n0 * 3, m2d, nvalid, buf, lane);
+        const fdgs_raster_deform_epilogue& e = a.epi;
+        float row[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[k] = 0.f;
+        if (i < a.P) {
+            row[0] = dmean[0]; row[1] = dmean[1]; row[2] = dmean[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) row[3 + k] = e.activate ? ds[k] * a.scales[3 * (size_t)i + k] : ds[k];     // d exp
+            if (e.activate) {
+                const float4 o = reinterpret_cast<const float4*>(a.rotations)[i];
+                const float nrm = e.rot_norm[i];
+                if (nrm > 1e-12f) {
+                    const float dot = o.x * dq[0] + o.y * dq[1] + o.z * dq[2] + o.w * dq[3];
+                    const float inv = 1.0f / nrm;
+                    row[6] = (dq[0] - o.x * dot) * inv; row[7] = (dq[1] - o.y * dot) * inv;
+                    row[8] = (dq[2] - o.z * dot) * inv; row[9] = (dq[3] - o.w * dot) * inv;
+                } else {  // below the F.normalize eps the division is by the constant 1e-12
+                    row[6] = dq[0] * 1e12f; row[7] = dq[1] * 1e12f; row[8] = dq[2] * 1e12f; row[9] = dq[3] * 1e12f;
+                }
+                const float o1 = a.opacities[i];
+                row[10] = dop * o1 * (1.f - o1);
+            } else {
+                row[6] = dq[0]; row[7] = dq[1]; row[8] = dq[2]; row[9] = dq[3];
+                row[10] = dop;
+            }
+        }
+        float* small = buf;              // [64][16]
+        float* sh = buf + 64 * 16;       // [64][48]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            reinterpret_cast<float4*>(small)[lane * 4 + k] = make_float4(row[4 * k], row[4 * k + 1], row[4 * k + 2], row[4 * k + 3]);
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            reinterpret_cast<float4*>(sh)[lane * 12 + k] = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
+            float4* G4 = reinterpret_cast<float4*>(e.G + (size_t)n0 * 64);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int v = j * 64 + lane, r = v >> 4, c4 = v & 15;
+                G4[v] = c4 < 4 ? reinterpret_cast<const float4*>(small)[r * 4 + c4] : reinterpret_cast<const float4*>(sh)[r * 12 + (c4 - 4)];
+            }
+        }
+        // identity paths (out = in + delta): accumulated into (or, e.assign, written as) the parameter gradients, block-linear
+        const bool asg = e.assign != 0;
+        if (e.d_shs_dc && e.d_shs_rest && e.shs_dc_stride == 48 && e.shs_rest_stride == 48 && e.d_shs_rest == e.d_shs_dc + 3) {
+            float4* d4 = reinterpret_cast<float4*>(e.d_shs_dc + (size_t)n0 * 48);   // one combined [N,16,3] tensor
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int v = j * 64 + lane;
+                if (v < nvalid * 12) {
+                    float4 y = reinterpret_cast<const float4*>(sh)[v];
+                    if (!asg) { const float4 x = d4[v]; y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w; }
+                    d4[v] = y;
+                }
+            }
+        } else {
+            if (e.d_shs_dc) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const int idx = j * 64 + lane, r = idx / 3, c = idx - 3 * r;
+                    if (r < nvalid) {
+                        float* q = e.d_shs_dc + (size_t)(n0 + r) * e.shs_dc_stride + c;
+                        *q = (asg ? 0.f : *q) + sh[r * 48 + c];
+                    }
+                }
+            }
+            if (e.d_shs_rest) {
+                if (asg && e.shs_rest_stride == 45) {      // a contiguous [N,15,3] tensor: the wave's block is 64 x 45 consecutive floats
+                    for (int j = 0; j < 45; j++) {
+                        const int idx = j * 64 + lane, r = idx / 45, c = idx - 45 * r;
+                        if (r < nvalid) e.d_shs_rest[(size_t)n0 * 45 + idx] = sh[r * 48 + 3 + c];
+                    }
+                } else {
+                    for (int j = 0; j < 45; j++) {
+                        const int idx = j * 64 + lane, r = idx / 45, c = idx - 45 * r;
+                        if (r < nvalid) {
+                            float* q = e.d_shs_rest + (size_t)(n0 + r) * e.shs_rest_stride + c;
+                            *q = (asg ? 0.f : *q) + sh[r * 48 + 3 + c];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int idx = j * 64 + lane, r = idx / 3, c = idx - 3 * r;
+            if (r < nvalid) {
+                if (e.d_xyz) e.d_xyz[(size_t)n0 * 3 + idx] = (asg ? 0.f : e.d_xyz[(size_t)n0 * 3 + idx]) + small[r * 16 + c];
+                if (e.d_scales) e.d_scales[(size_t)n0 * 3 + idx] = (asg ? 0.f : e.d_scales[(size_t)n0 * 3 + idx]) + small[r * 16 + 3 + c];
+            }
+        }
+        if (e.d_rotations) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = j * 64 + lane, r = idx >> 2, c = idx & 3;
+                if (r < nvalid) e.d_rotations[(size_t)n0 * 4 + idx] = (asg ? 0.f : e.d_rotations[(size_t)n0 * 4 + idx]) + small[r * 16 + 6 + c];
+            }
+        }
+        if (e.d_opacity && lane < nvalid) e.d_opacity[i] = (asg ? 0.f : e.d_opacity[i]) + small[lane * 16 + 10];
+        return;
     }
     wave_store_rows<3>(a.dL_dmeans2D + (size_t)n0 * 3, m2d, nvalid, buf, lane);
     wave_store_rows<3>(a.dL_dcolors + (size_t)n0 * 3, drgb, nvalid, buf, lane);
@@ -303,7 +416,18 @@ int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, 
     a.dL_dmeans2D = g->dL_dmeans2D; a.gacc = g->scratch_acc; a.dL_dopacity = g->dL_dopacity;
     a.dL_dcolors = g->dL_dcolors; a.dL_dmeans3D = g->dL_dmeans3D; a.dL_dsh = g->dL_dsh; a.dL_dscales = g->dL_dscales;
     a.dL_drot = g->dL_drotations; a.dL_dcov3D = g->dL_dcov3D;
-    { FDGS_TIMED("preprocess_bwd", stream); hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
+    a.opacities = p->opacities;
+    if (g->deform_epilogue) {
+        const fdgs_raster_deform_epilogue* e = g->deform_epilogue;
+        FDGS_REQUIRE(p->shs && p->sh_coeffs == 16 && p->scales && p->rotations && !p->cov3D_precomp,
+                     "deform_epilogue needs SH (16 coefficients) and scale/rotation inputs");
+        FDGS_REQUIRE(e->G && e->Npad >= p->P && e->Npad % 128 == 0 && (!e->activate || e->rot_norm), "bad deform_epilogue");
+        a.epi = *e;
+        { FDGS_TIMED("preprocess_bwd", stream); hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(cdiv(e->Npad, 256)), dim3(256), 0, stream, a); }
+        FDGS_LAUNCH_CHECK("preprocess_bwd", p->debug, stream);
+        return FDGS_OK;
+    }
+    { FDGS_TIMED("preprocess_bwd", stream); hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_bwd", p->debug, stream);
     return FDGS_OK;
 }

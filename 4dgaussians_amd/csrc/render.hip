@@ -282,10 +282,14 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(g && geom && img && (binning || R == 0), "NULL buffer");
-    FDGS_REQUIRE(g->dL_dcolor && g->dL_dmeans2D && g->dL_dmeans3D && g->dL_dopacity && g->dL_dcolors && g->dL_dcov3D &&
-                     g->scratch_acc, "required gradient buffer is NULL");
-    FDGS_REQUIRE(!p->shs || g->dL_dsh, "dL_dsh required when shs is given");
-    FDGS_REQUIRE(p->cov3D_precomp || (g->dL_dscales && g->dL_drotations), "dL_dscales/dL_drotations required");
+    if (g->deform_epilogue) {     // the per-Gaussian results go to the deformation backward's buffers instead (include/fdgs.h)
+        FDGS_REQUIRE(g->dL_dcolor && g->dL_dmeans2D && g->scratch_acc, "required gradient buffer is NULL");
+    } else {
+        FDGS_REQUIRE(g->dL_dcolor && g->dL_dmeans2D && g->dL_dmeans3D && g->dL_dopacity && g->dL_dcolors && g->dL_dcov3D &&
+                         g->scratch_acc, "required gradient buffer is NULL");
+        FDGS_REQUIRE(!p->shs || g->dL_dsh, "dL_dsh required when shs is given");
+        FDGS_REQUIRE(p->cov3D_precomp || (g->dL_dscales && g->dL_drotations), "dL_dscales/dL_drotations required");
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t P = (size_t)p->P;
     if (P == 0) return FDGS_OK;

@@ -245,105 +245,146 @@ def _aabb_to_host(aabb):
     return vals
 
 
+class _FwdState:
+    """What one deformation forward leaves behind for its backward (shared by _DeformFunction and the fused render Function)."""
+    __slots__ = ("cfg", "p", "keep", "saved_act", "o_xyz", "o_sc", "o_rot", "o_op", "o_sh", "o_norm", "shapes", "plane_shapes")
+
+
+def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, rest, want_backward):
+    """Runs fdgs_deform_fwd.  `want_backward`: a backward will follow (grad mode on and some input requires grad): the forward
+    then also leaves the activations behind (SAVE_ACTIVATIONS)."""
+    L = _lib.lib()
+    dev = xyz.device
+    if dev.type != "cuda":
+        raise _lib.FdgsError("the deformation kernels run on the GPU only")
+    nplanes = cfg["L"] * 6
+    planes_in, mlp_in = rest[:nplanes], rest[nplanes:]
+    c = lambda t: None if t is None else t.detach().float().contiguous()
+    xyz_, scales_, rot_, op_ = c(xyz), c(scales), c(rotations), c(opacity)
+    sh_a_, sh_b_ = c(sh_a), c(sh_b)
+    t_ = None if t_tensor is None else c(t_tensor).reshape(-1)
+    planes = [_cl(p.detach()) for p in planes_in]
+    mlp = [c(m) for m in mlp_in]
+    N = xyz_.shape[0]
+    st = _FwdState()
+    st.keep = []
+    p = _fill_params(cfg, t_scalar, xyz_, scales_, rot_, op_, sh_a_, sh_b_, t_, _aabb_to_host(aabb), planes, mlp, st.keep)
+    out = DeformOut()
+    st.o_xyz, st.o_sc = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+    st.o_rot, st.o_op = torch.empty(N, 4, device=dev), torch.empty(N, 1, device=dev)
+    st.o_sh = torch.empty(N, 16, 3, device=dev)
+    st.o_norm = torch.empty(N, device=dev) if cfg["activate"] else None
+    out.xyz, out.scales, out.rotations, out.opacity, out.shs, out.rot_norm = ptr(st.o_xyz), ptr(st.o_sc), ptr(st.o_rot), ptr(st.o_op), ptr(st.o_sh), ptr(st.o_norm)
+    saved = None
+    if cfg["save"] and want_backward:
+        nbytes = _lib.c_size_t()
+        check(L.fdgs_deform_saved_bytes(p, nbytes))
+        saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out.saved = ptr(saved)
+    st.saved_act = saved
+    check(L.fdgs_deform_fwd(stream_ptr(), p, out))
+    st.cfg, st.p = cfg, p
+    st.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape, sh_b=None if sh_b is None else sh_b.shape)
+    st.plane_shapes = [tuple(q.shape) for q in planes_in]
+    return st
+
+
+class _BwdBuffers:
+    __slots__ = ("g", "arena", "d_xyz", "d_sc", "d_rot", "d_op", "d_sha", "d_shb", "d_planes", "d_mlp", "scratch", "keep")
+
+
+def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False):
+    """Allocates the gradient arena and the scratch of fdgs_deform_bwd and fills fdgs_deform_grads (without the upstream gradients).
+    The arena is zero-filled (every kernel accumulates); with `identity_assigned` the six per-Gaussian arrays at its head are left
+    uninitialised -- the rasterizer backward's epilogue ASSIGNS them (fdgs_raster_deform_epilogue::assign) before anything adds to them.
+    Returns the buffers; `backward_run` launches."""
+    L = _lib.lib()
+    cfg, p = st.cfg, st.p
+    xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, planes, mlp = st.keep[0]
+    dev, N = xyz.device, xyz.shape[0]
+    b = _BwdBuffers()
+    g = DeformGrads()
+    g.out_scales, g.out_rotations, g.out_opacity, g.rot_norm = ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(st.o_norm)
+    # every outgoing gradient is accumulated into (+=) by the kernels: ONE zero-filled arena, carved into views
+    # (40 separate torch.zeros launches cost more than the fill itself at 150 frames/s)
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1)]
+    shapes += [(N, 16, 3)] if sh_b is None else [(N, 1, 3), (N, 15, 3)]
+    n_fixed = len(shapes)
+    shapes += [(1, s_[2], s_[3], s_[1]) for s_ in st.plane_shapes]          # channels-last memory order
+    shapes += [tuple(m.shape) for m in mlp]
+    sizes = [(int(torch.Size(s_).numel()) + 63) // 64 * 64 for s_ in shapes]  # 256-B aligned slices
+    if identity_assigned:
+        arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        arena[sum(sizes[:n_fixed]):].zero_()
+    else:
+        arena = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    views, off = [], 0
+    for s_, n_ in zip(shapes, sizes):
+        views.append(arena[off:off + int(torch.Size(s_).numel())].view(s_))
+        off += n_
+    b.arena = arena
+    b.d_xyz, b.d_sc, b.d_rot, b.d_op = views[:4]
+    if sh_b is None:
+        b.d_sha, b.d_shb = views[4], None
+        g.d_shs_dc, g.d_shs_rest = b.d_sha.data_ptr(), b.d_sha.data_ptr() + 12
+    else:
+        b.d_sha, b.d_shb = views[4], views[5]
+        g.d_shs_dc, g.d_shs_rest = b.d_sha.data_ptr(), b.d_shb.data_ptr()
+    g.d_xyz, g.d_scales, g.d_rotations, g.d_opacity = ptr(b.d_xyz), ptr(b.d_sc), ptr(b.d_rot), ptr(b.d_op)
+    nplanes = len(st.plane_shapes)
+    b.d_planes = [v.permute(0, 3, 1, 2) for v in views[n_fixed:n_fixed + nplanes]]  # logical [1,C,H,W], channels_last
+    for l in range(cfg["L"]):
+        for k in range(6):
+            g.d_planes[l][k] = b.d_planes[l * 6 + k].data_ptr()
+    b.d_mlp = list(views[n_fixed + nplanes:])
+    g.d_w0, g.d_b0 = b.d_mlp[0].data_ptr(), b.d_mlp[1].data_ptr()
+    for h in range(NUM_HEADS):
+        g.d_w1[h], g.d_b1[h] = b.d_mlp[2 + 4 * h].data_ptr(), b.d_mlp[3 + 4 * h].data_ptr()
+        g.d_w2[h], g.d_b2[h] = b.d_mlp[4 + 4 * h].data_ptr(), b.d_mlp[5 + 4 * h].data_ptr()
+    nbytes = _lib.c_size_t()
+    check(L.fdgs_deform_bwd_scratch_bytes(p, nbytes))
+    b.scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    g.scratch = ptr(b.scratch)
+    g.saved = ptr(st.saved_act)
+    b.g = g
+    return b
+
+
+def backward_run(st, b):
+    """Launches fdgs_deform_bwd on prepared buffers and returns the gradients in _DeformFunction's input order (after cfg, t_scalar)."""
+    check(_lib.lib().fdgs_deform_bwd(stream_ptr(), st.p, b.g))
+    cfg, sh = st.cfg, st.shapes
+    d_mlp = b.d_mlp
+    for h in range(NUM_HEADS):  # parameters of a disabled head receive no gradient (as under autograd)
+        if not cfg["head_on"][h]:
+            d_mlp[2 + 4 * h:6 + 4 * h] = [None] * 4
+    return (b.d_xyz, b.d_sc.reshape(sh["scales"]), b.d_rot.reshape(sh["rot"]), b.d_op.reshape(sh["op"]),
+            b.d_sha.reshape(sh["sh_a"]), None if b.d_shb is None else b.d_shb.reshape(sh["sh_b"]), None, None,
+            *b.d_planes, *d_mlp)
+
+
 class _DeformFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, *rest):
-        L = _lib.lib()
-        dev = xyz.device
-        if dev.type != "cuda":
-            raise _lib.FdgsError("the deformation kernels run on the GPU only")
-        nplanes = cfg["L"] * 6
-        planes_in, mlp_in = rest[:nplanes], rest[nplanes:]
-        c = lambda t: None if t is None else t.detach().float().contiguous()
-        xyz_, scales_, rot_, op_ = c(xyz), c(scales), c(rotations), c(opacity)
-        sh_a_, sh_b_ = c(sh_a), c(sh_b)
-        t_ = None if t_tensor is None else c(t_tensor).reshape(-1)
-        planes = [_cl(p.detach()) for p in planes_in]
-        mlp = [c(m) for m in mlp_in]
-        N = xyz_.shape[0]
-        keep = []
-        p = _fill_params(cfg, t_scalar, xyz_, scales_, rot_, op_, sh_a_, sh_b_, t_, _aabb_to_host(aabb), planes, mlp, keep)
-        out = DeformOut()
-        o_xyz, o_sc = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
-        o_rot, o_op = torch.empty(N, 4, device=dev), torch.empty(N, 1, device=dev)
-        o_sh = torch.empty(N, 16, 3, device=dev)
-        o_norm = torch.empty(N, device=dev) if cfg["activate"] else None
-        out.xyz, out.scales, out.rotations, out.opacity, out.shs, out.rot_norm = ptr(o_xyz), ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_sh), ptr(o_norm)
-        saved = None
-        if cfg["save"] and any(ctx.needs_input_grad):
-            nbytes = _lib.c_size_t()
-            check(L.fdgs_deform_saved_bytes(p, nbytes))
-            saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        out.saved = ptr(saved)
-        ctx.saved_act = saved
-        check(L.fdgs_deform_fwd(stream_ptr(), p, out))
-        ctx.cfg, ctx.t_scalar, ctx.p, ctx.keep = cfg, t_scalar, p, keep
+        st = forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, rest, any(ctx.needs_input_grad))
+        ctx.st = st
+        ctx.saved_act = st.saved_act
         # outputs the backward needs go through save_for_backward: keeping them as plain attributes makes a reference
         # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC breaks -- with ~1 GB of per-frame buffers
         # hanging on it (saved activations) every frame then costs a fresh 1-GB hipMalloc (30 ms)
-        ctx.save_for_backward(o_sc, o_rot, o_op)
-        ctx.o_norm = o_norm
-        ctx.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape,
-                          sh_b=None if sh_b is None else sh_b.shape)
-        ctx.plane_shapes = [tuple(q.shape) for q in planes_in]
-        ctx.needs = ctx.needs_input_grad
+        ctx.save_for_backward(st.o_sc, st.o_rot, st.o_op)
+        outs = (st.o_xyz, st.o_sc, st.o_rot, st.o_op, st.o_sh)
+        st.o_xyz = st.o_sc = st.o_rot = st.o_op = st.o_sh = None
         ctx.set_materialize_grads(False)   # unused outputs arrive as None -> NULL pointers, which the kernels skip
-        return o_xyz, o_sc, o_rot, o_op, o_sh
+        return outs
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_rot, g_op, g_sh):
-        L = _lib.lib()
-        cfg, p = ctx.cfg, ctx.p
-        xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, planes, mlp = ctx.keep[0]
+        st = ctx.st
         o_sc, o_rot, o_op = ctx.saved_tensors
-        o_norm = ctx.o_norm
-        dev, N = xyz.device, xyz.shape[0]
+        b = backward_prepare(st, o_sc, o_rot, o_op)
         c = lambda t: None if t is None else t.float().contiguous()
-        g = DeformGrads()
         gx, gs, gr, go, gsh = c(g_xyz), c(g_sc), c(g_rot), c(g_op), c(g_sh)
+        g = b.g
         g.g_xyz, g.g_scales, g.g_rotations, g.g_opacity, g.g_shs = ptr(gx), ptr(gs), ptr(gr), ptr(go), ptr(gsh)
-        g.out_scales, g.out_rotations, g.out_opacity, g.rot_norm = ptr(o_sc), ptr(o_rot), ptr(o_op), ptr(o_norm)
-        # every outgoing gradient is accumulated into (+=) by the kernels: ONE zero-filled arena, carved into views
-        # (40 separate torch.zeros launches cost more than the fill itself at 150 frames/s)
-        shapes = [(N, 3), (N, 3), (N, 4), (N, 1)]
-        shapes += [(N, 16, 3)] if sh_b is None else [(N, 1, 3), (N, 15, 3)]
-        n_fixed = len(shapes)
-        shapes += [(1, s_[2], s_[3], s_[1]) for s_ in ctx.plane_shapes]          # channels-last memory order
-        shapes += [tuple(m.shape) for m in mlp]
-        sizes = [(int(torch.Size(s_).numel()) + 63) // 64 * 64 for s_ in shapes]  # 256-B aligned slices
-        arena = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
-        views, off = [], 0
-        for s_, n_ in zip(shapes, sizes):
-            views.append(arena[off:off + int(torch.Size(s_).numel())].view(s_))
-            off += n_
-        d_xyz, d_sc, d_rot, d_op = views[:4]
-        if sh_b is None:
-            d_sha, d_shb = views[4], None
-            g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_sha.data_ptr() + 12
-        else:
-            d_sha, d_shb = views[4], views[5]
-            g.d_shs_dc, g.d_shs_rest = d_sha.data_ptr(), d_shb.data_ptr()
-        g.d_xyz, g.d_scales, g.d_rotations, g.d_opacity = ptr(d_xyz), ptr(d_sc), ptr(d_rot), ptr(d_op)
-        nplanes = len(ctx.plane_shapes)
-        d_planes = [v.permute(0, 3, 1, 2) for v in views[n_fixed:n_fixed + nplanes]]  # logical [1,C,H,W], channels_last
-        for l in range(cfg["L"]):
-            for k in range(6):
-                g.d_planes[l][k] = d_planes[l * 6 + k].data_ptr()
-        d_mlp = list(views[n_fixed + nplanes:])
-        g.d_w0, g.d_b0 = d_mlp[0].data_ptr(), d_mlp[1].data_ptr()
-        for h in range(NUM_HEADS):
-            g.d_w1[h], g.d_b1[h] = d_mlp[2 + 4 * h].data_ptr(), d_mlp[3 + 4 * h].data_ptr()
-            g.d_w2[h], g.d_b2[h] = d_mlp[4 + 4 * h].data_ptr(), d_mlp[5 + 4 * h].data_ptr()
-        nbytes = _lib.c_size_t()
-        check(L.fdgs_deform_bwd_scratch_bytes(p, nbytes))
-        scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        g.scratch = ptr(scratch)
-        g.saved = ptr(ctx.saved_act)
-        check(L.fdgs_deform_bwd(stream_ptr(), p, g))
-        for h in range(NUM_HEADS):  # parameters of a disabled head receive no gradient (as under autograd)
-            if not cfg["head_on"][h]:
-                d_mlp[2 + 4 * h:6 + 4 * h] = [None] * 4
-        sh = ctx.shapes
-        return (None, None, d_xyz, d_sc.reshape(sh["scales"]), d_rot.reshape(sh["rot"]), d_op.reshape(sh["op"]),
-                d_sha.reshape(sh["sh_a"]), None if d_shb is None else d_shb.reshape(sh["sh_b"]), None, None,
-                *d_planes, *d_mlp)
+        return (None, None) + backward_run(st, b)

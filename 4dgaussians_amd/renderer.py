@@ -11,8 +11,61 @@ import math
 
 import torch
 
+from . import _lib
 from . import deformation as _deformation
+from . import rasterizer as _rasterizer
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+# Fused fine stage: deformation and rasterizer behind ONE autograd node, so that the rasterizer backward's per-Gaussian chain rule
+# writes straight into the deformation backward's buffers (fdgs_raster_deform_epilogue) instead of handing five gradient tensors
+# through autograd to a separate packing kernel.  FDGS_FUSED_BACKWARD=0 keeps the two-node form (A/B, and what the tests compare with).
+FUSED_BACKWARD = __import__("os").environ.get("FDGS_FUSED_BACKWARD", "1") != "0"
+
+
+class _FusedRenderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, t_scalar, raster_settings, means2D, xyz, scales, rotations, opacity, sh_a, sh_b, aabb, *rest):
+        st = _deformation.forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, None, aabb, rest,
+                                       any(ctx.needs_input_grad))
+        color, radii, depth, rstate = _rasterizer.rasterize_forward(raster_settings, st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None)
+        ctx.st, ctx.rstate = st, rstate
+        ctx.save_for_backward(st.o_sc, st.o_rot, st.o_op)       # (see _DeformFunction.forward: no reference cycle through ctx)
+        st.o_xyz = st.o_sc = st.o_rot = st.o_op = st.o_sh = None
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth):
+        st, rstate = ctx.st, ctx.rstate
+        n_in = 11 + len(st.plane_shapes) + len(st.keep[0][8])
+        if grad_color is None and grad_depth is None:
+            return (None,) * n_in
+        L = _lib.lib()
+        o_sc, o_rot, o_op = ctx.saved_tensors
+        b = _deformation.backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=True)
+        p = rstate.params
+        dev, P = b.d_xyz.device, p.P
+        if grad_color is None:
+            grad_color = torch.zeros(3, p.H, p.W, device=dev)
+        f = lambda t: None if t is None else t.float().contiguous()
+        grad_color, grad_depth = f(grad_color), f(grad_depth)
+        g = _lib.RasterGrads()
+        g_means2D, acc = torch.empty(P, 3, device=dev), torch.empty(P, 16, device=dev)
+        g.dL_dcolor, g.dL_ddepth, g.dL_dmeans2D, g.scratch_acc = _lib.ptr(grad_color), _lib.ptr(grad_depth), _lib.ptr(g_means2D), _lib.ptr(acc)
+        epi = _lib.RasterDeformEpilogue()
+        epi.activate, epi.Npad = 1, (P + 127) // 128 * 128
+        epi.rot_norm, epi.G = _lib.ptr(st.o_norm), _lib.ptr(b.scratch)
+        epi.d_xyz, epi.d_scales, epi.d_rotations, epi.d_opacity = b.g.d_xyz, b.g.d_scales, b.g.d_rotations, b.g.d_opacity
+        epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
+        epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
+        epi.assign = 1
+        g.deform_epilogue = _lib.ctypes.pointer(epi)
+        _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
+                                     rstate.num_rendered, g))
+        b.g.packed_rows_ready = 1
+        grads = _deformation.backward_run(st, b)       # (d_xyz, d_sc, d_rot, d_op, d_sha, d_shb, None [time], None [aabb], planes..., mlp...)
+        return (None, None, None, g_means2D) + grads[:6] + grads[7:]
 
 
 def _dev(t, device):
@@ -56,7 +109,20 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         rotations_final = None if rotations is None else pc.rotation_activation(rotations)
         opacity_final = pc.opacity_activation(opacity)
     elif "fine" in stage:
-        if fused:
+        if fused and FUSED_BACKWARD and override_color is None and not pipe.convert_SHs_python:
+            # deformation + rasterizer as one autograd node (see _FusedRenderFunction)
+            net = pc._deformation
+            planes, mlp = _deformation._collect(net)
+            dn = net.deformation_net
+            cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
+                       head_on=_deformation._head_on(dn.args), activate=True,
+                       save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()))
+            rendered_image, radii, depth = _FusedRenderFunction.apply(
+                cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
+                dn.grid.aabb, *planes, *mlp)
+            return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                    "radii": radii, "depth": depth}
+        elif fused:
             means3D_final, scales_final, rotations_final, opacity_final, shs_final = _deformation.deform(
                 pc._deformation, means3D, scales, rotations, opacity, shs_dc=pc._features_dc, shs_rest=pc._features_rest,
                 time=frame_time, activate=True)

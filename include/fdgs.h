@@ -95,6 +95,26 @@ int fdgs_bin_sort(void* stream, const fdgs_raster_params* p, void* geom, void* b
 int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom, const void* binning, void* img,
                     uint32_t num_rendered, float* out_color, float* out_depth);
 
+/* Optional epilogue of fdgs_raster_bwd for the fused render() path (deformation -> rasterizer): the per-Gaussian chain rule
+ * writes its results straight in the form fdgs_deform_bwd consumes -- the packed pre-activation output-gradient rows G[Npad][64]
+ * (columns 0-2 position, 3-5 log-scale, 6-9 raw quaternion, 10 opacity logit, 16-63 SH; activation Jacobians of
+ * gaussian_renderer/__init__.py:97-99 applied when `activate`) and the identity paths of `out = in + delta` accumulated into the
+ * parameter gradients -- instead of dL_dmeans3D / dL_dscales / dL_drotations / dL_dopacity / dL_dsh, which are then not written.
+ * G is the START of the scratch buffer later handed to fdgs_deform_bwd (fdgs_deform_grads::scratch) with packed_rows_ready = 1.
+ * Saves one kernel and a write + read of 236 bytes per Gaussian between the two backward stages. */
+typedef struct fdgs_raster_deform_epilogue {
+    int activate;                /* the scales / rotations / opacities the rasterizer received are exp / normalize / sigmoid outputs */
+    int Npad;                    /* rows of G: fdgs_deform_bwd's padded Gaussian count (multiple of 128, >= P) */
+    const float* rot_norm;       /* [P] norm of the raw quaternion (activate = 1), fdgs_deform_out::rot_norm */
+    float* G;                    /* [Npad,64], every row written (rows >= P zero) */
+    float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity;   /* identity paths (any may be NULL) */
+    float* d_shs_dc; float* d_shs_rest;                                    /* strides in floats as in fdgs_deform_params */
+    int shs_dc_stride; int shs_rest_stride;
+    int assign;                  /* 0: the identity paths are accumulated (+=, caller zero-fills); 1: they are ASSIGNED (=): the caller
+                                    needs no zero fill of these six arrays -- fdgs_deform_bwd, which runs afterwards, only ever adds to
+                                    d_xyz (the HexPlane coordinate gradient) */
+} fdgs_raster_deform_epilogue;
+
 typedef struct fdgs_raster_grads {
     const float* dL_dcolor;  /* [3,H,W] */
     const float* dL_ddepth;  /* opt [1,H,W] */
@@ -109,6 +129,8 @@ typedef struct fdgs_raster_grads {
     float* dL_dcov3D;        /* [P,6] */
     /* scratch owned by the caller: [P,16] floats (one 64-byte gradient line per Gaussian, see render.hip) */
     float* scratch_acc;
+    /* opt: see above (requires shs + scales/rotations inputs, 16 SH coefficients) */
+    const fdgs_raster_deform_epilogue* deform_epilogue;
 } fdgs_raster_grads;
 
 /* Backward of stages 4 and 1 (back-to-front blending gradients, then per-Gaussian chain rule). */
@@ -201,6 +223,9 @@ typedef struct fdgs_deform_grads {
     void* scratch;
     /* opt: the `saved` buffer the forward of the SAME parameters / inputs filled (NULL: everything is recomputed) */
     const void* saved;
+    /* 1: `scratch` already starts with the packed gradient rows and the identity paths were applied (fdgs_raster_bwd's epilogue);
+     * the g_* / out_* / rot_norm pointers above are then ignored */
+    int packed_rows_ready;
 } fdgs_deform_grads;
 
 int fdgs_deform_bwd_scratch_bytes(const fdgs_deform_params* p, size_t* bytes);

@@ -62,5 +62,5 @@ def test_struct_field_order_matches_header(L):
         return out
     for cname, cls in (("fdgs_raster_params", L.RasterParams), ("fdgs_raster_grads", L.RasterGrads),
                        ("fdgs_deform_params", L.DeformParams), ("fdgs_deform_out", L.DeformOut),
-                       ("fdgs_deform_grads", L.DeformGrads)):
+                       ("fdgs_deform_grads", L.DeformGrads), ("fdgs_raster_deform_epilogue", L.RasterDeformEpilogue)):
         assert fields(cname) == [f[0] for f in cls._fields_], cname
