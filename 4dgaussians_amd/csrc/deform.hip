@@ -1807,10 +1807,31 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
                     const int ox = ax == 0 ? org0 : org1, oy = bx == 1 ? org1 : org2;
                     const int bin = k == 0 ? 0 : 1;
                     const uint32_t kbit = 1u << k;
+                    // the two waves of a plane split the row lists where the Gaussian count is halved (the rows fill up from the
+                    // window origin: a fixed split at row 8 left one wave with 80 % of the work): lists [0, rs) and [rs, 15), each at
+                    // most LISTS long -- rs in [last - LISTS + 1, LISTS], `last` = last non-empty list
+                    int base = 0, lend = 15;
+                    if (NWV == 8) {
+                        const int c = lane < 15 ? s_cnt[bin * 16 + lane] : 0;
+                        int pre = c;
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(pre, o, 64); if ((lane & 15) >= o) pre += u; }
+                        const int total = __shfl(pre, 15, 64);
+                        const uint64_t half = __ballot(lane < 16 && 2 * pre >= total);          // first list whose prefix reaches half
+                        const uint64_t nonz = __ballot(lane < 16 && c > 0);
+                        const int last = nonz ? 63 - __builtin_clzll(nonz) : 0;
+                        int rs = half ? __builtin_ctzll(half) + 1 : LISTS;
+                        const int lo = last - LISTS + 1;
+                        rs = rs < lo ? lo : rs;
+                        rs = rs > LISTS ? LISTS : rs;
+                        rs = rs < 1 ? 1 : rs;
+                        base = hh ? rs : 0;
+                        lend = hh ? 15 : rs;
+                    }
 #pragma nounroll
                     for (int hf = 0; hf < NH; hf++) {
                         // the previous window of this wave: accumulator register j of lane (gk, il) is texel x = ox + 4 gk + j of window
-                        // row 8 hh + rr, channel il
+                        // row base + rr, channel il
                         if (pend_rows) {
 #pragma unroll
                             for (int rr = 0; rr < NACC; rr++) {
@@ -1831,8 +1852,8 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
                         uint32_t rows_any = 0;
 #pragma unroll
                         for (int rr = 0; rr < LISTS; rr++) {
-                            const int r = LISTS * hh + rr;             // list of window row r feeds rows r and r + 1 (r <= 14)
-                            const int nr = r <= 14 ? s_cnt[bin * 16 + r] : 0;
+                            const int r = base + rr;                   // list of window row r feeds rows r and r + 1 (r <= 14)
+                            const int nr = r < lend ? s_cnt[bin * 16 + r] : 0;
                             const uint8_t* lst = s_list + (bin * 16 + r) * G;
                             // two steps (8 Gaussians) per iteration; the list bytes of the next iteration are requested before this
                             // iteration's operands, and all operand requests before the first MFMA
@@ -1859,7 +1880,7 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
                             }
                             if (nr > 0) rows_any |= 3u << rr;
                         }
-                        pend_rows = rows_any; pend_dP = dP; pend_ox = ox; pend_oy = oy + LISTS * hh; pend_Wd = p.res[lvl][ax]; pend_Hd = p.res[lvl][bx];
+                        pend_rows = rows_any; pend_dP = dP; pend_ox = ox; pend_oy = oy + base; pend_Wd = p.res[lvl][ax]; pend_Hd = p.res[lvl][bx];
                         pend_hf = hf;
                         D4_TICK(3);
                         if (!DEFER && pend_rows) {
@@ -1901,10 +1922,16 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
                             nba = s_dv[(k * G + gn) * C + hf * 16 + il]; nbb = s_dv[(k * G + gn + 4) * C + hf * 16 + il];
                             __builtin_amdgcn_sched_barrier(0);
                             const int ra = __float_as_int(cxa.x) - x0, rb = __float_as_int(cxb.x) - x0;    // (Gaussians outside the two tiles have dv = 0)
-                            acc0 = mfma16(il == ra ? cxa.y : (il == ra + 1 ? cxa.z : 0.f), bva, acc0);
-                            acc1 = mfma16(il + 16 == ra ? cxa.y : (il + 16 == ra + 1 ? cxa.z : 0.f), bva, acc1);
-                            acc0 = mfma16(il == rb ? cxb.y : (il == rb + 1 ? cxb.z : 0.f), bvb, acc0);
-                            acc1 = mfma16(il + 16 == rb ? cxb.y : (il + 16 == rb + 1 ? cxb.z : 0.f), bvb, acc1);
+                            // a tile that none of the iteration's eight Gaussians touches is skipped (wave-uniform): a compact chunk
+                            // usually sits inside one of the two
+                            if (__ballot(ra <= 15 || rb <= 15)) {
+                                acc0 = mfma16(il == ra ? cxa.y : (il == ra + 1 ? cxa.z : 0.f), bva, acc0);
+                                acc0 = mfma16(il == rb ? cxb.y : (il == rb + 1 ? cxb.z : 0.f), bvb, acc0);
+                            }
+                            if (__ballot((ra >= 15 && ra <= 31) || (rb >= 15 && rb <= 31))) {
+                                acc1 = mfma16(il + 16 == ra ? cxa.y : (il + 16 == ra + 1 ? cxa.z : 0.f), bva, acc1);
+                                acc1 = mfma16(il + 16 == rb ? cxb.y : (il + 16 == rb + 1 ? cxb.z : 0.f), bvb, acc1);
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -2366,8 +2393,10 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
         // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
         // atomics on ~128 hot lines, is 4x slower than scattered atomics)
-        const int lds_budget = use_mfma ? 160 * 1024 - fixed_floats * 4
-                                        : (tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0);
+        int lds_budget = use_mfma ? 160 * 1024 - fixed_floats * 4
+                                  : (tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0);
+        if (use_mfma && tunable("FDGS_D4_ROWS_KB", -1) >= 0 && tunable("FDGS_D4_ROWS_KB", -1) * 1024 < lds_budget)
+            lds_budget = tunable("FDGS_D4_ROWS_KB", -1) * 1024;     // (tests: time rows that do not fit take the global-atomic path)
         int used = 0;
         for (int l = 0; l < FDGS_MAX_LEVELS; l++)
             for (int sl = 0; sl < 3; sl++) ga.lds_off[l][sl] = -1;

@@ -426,3 +426,15 @@ def test_plane_grad_mfma_splat_vs_oracle_on_ordered_input(cfg, n, t, monkeypatch
     errs = [rel_l2(a.cpu().numpy(), b.numpy().reshape(a.shape)) for a, b in zip(g, g_ref)]
     print(f"[{cfg} n={n}] splat vs oracle: xyz {errs[0]:.1e}, planes max {max(errs[1:]):.1e} ({int(risky.sum())} near-kink rows masked)")
     assert errs[0] < 1e-3 and max(errs[1:]) < 1e-4
+
+
+@pytest.mark.parametrize("rows_kb", [0, 20])
+def test_plane_grad_mfma_time_rows_that_do_not_fit_lds(rows_kb, monkeypatch):
+    """When the private time rows of a level do not fit the workgroup's LDS (large planes, many levels) that level's time planes take
+    global atomics in the miss pass: forced here by capping the budget (0 KB: no level fits; 20 KB: level 0 fits, level 1 does not)."""
+    monkeypatch.setenv("FDGS_D4_ROWS_KB", str(rows_kb))
+    a, _ = _plane_grads("dynerf_default", 6000, "hilbert", 0.61, True, monkeypatch)
+    monkeypatch.delenv("FDGS_D4_ROWS_KB")
+    b, _ = _plane_grads("dynerf_default", 6000, "hilbert", 0.61, False, monkeypatch)
+    errs = [rel_l2(x.numpy(), y.numpy()) for x, y in zip(a, b)]
+    assert errs[0] < 1e-5 and max(errs[1:]) < 2e-5
