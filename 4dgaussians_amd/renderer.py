@@ -20,6 +20,7 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 # writes straight into the deformation backward's buffers (fdgs_raster_deform_epilogue) instead of handing five gradient tensors
 # through autograd to a separate packing kernel.  FDGS_FUSED_BACKWARD=0 keeps the two-node form (A/B, and what the tests compare with).
 FUSED_BACKWARD = __import__("os").environ.get("FDGS_FUSED_BACKWARD", "1") != "0"
+EPILOGUE_ASSIGN = True     # False: the epilogue accumulates (+=) into a zero-filled arena (the C-ABI's other mode; tests compare both)
 
 
 class _FusedRenderFunction(torch.autograd.Function):
@@ -43,7 +44,7 @@ class _FusedRenderFunction(torch.autograd.Function):
             return (None,) * n_in
         L = _lib.lib()
         o_sc, o_rot, o_op = ctx.saved_tensors
-        b = _deformation.backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=True)
+        b = _deformation.backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=EPILOGUE_ASSIGN)
         p = rstate.params
         dev, P = b.d_xyz.device, p.P
         if grad_color is None:
@@ -59,7 +60,7 @@ class _FusedRenderFunction(torch.autograd.Function):
         epi.d_xyz, epi.d_scales, epi.d_rotations, epi.d_opacity = b.g.d_xyz, b.g.d_scales, b.g.d_rotations, b.g.d_opacity
         epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
         epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
-        epi.assign = 1
+        epi.assign = 1 if EPILOGUE_ASSIGN else 0
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                      rstate.num_rendered, g))

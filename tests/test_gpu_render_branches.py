@@ -218,3 +218,30 @@ def test_fused_backward_node_equals_two_node_form(cfg, monkeypatch):
     print(f"[{cfg}] fused vs two-node: worst gradient rel-L2 {worst[0]:.1e} ({worst[1]})")
     assert worst[0] < 2e-5
     assert rel_l2(va.cpu().numpy(), vb.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 70, 129, 1000])
+@pytest.mark.parametrize("assign", [True, False])
+def test_fused_backward_small_and_ragged_counts_both_epilogue_modes(n, assign, monkeypatch):
+    """Gaussian counts that do not fill a 64-row wave block / a 128-row padded block, and both modes of the rasterizer backward's
+    deformation epilogue (assign into an uninitialised arena / accumulate into a zero-filled one), against the two-node form."""
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    cam = synthetic.make_camera(96, 80, theta_deg=15.0, time=0.3).to(dev)
+    w = torch.randn(3, 80, 96, generator=torch.Generator().manual_seed(9)).to(dev)
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(fd.renderer, "FUSED_BACKWARD", fused)
+        monkeypatch.setattr(fd.renderer, "EPILOGUE_ASSIGN", assign)
+        pc = _model(n, "dynerf_default", seed=31, boost=2.5)
+        # poison the caching allocator's free blocks: an "assign" epilogue that forgot a row would hand back garbage, not zeros
+        junk = torch.full((4_000_000,), float("nan"), device=dev)
+        del junk
+        res = fd.render(cam, pc, _Pipe(), torch.zeros(3, device=dev), stage="fine")
+        (res["render"] * w).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in pc.named_parameters() if p.grad is not None})
+    a, b = grads
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert rel_l2(a[k].cpu().numpy(), b[k].cpu().numpy()) < 2e-5, (k, n, assign)
