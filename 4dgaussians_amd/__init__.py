@@ -8,10 +8,10 @@ The HIP library is loaded lazily on first use and there is no CPU fallback.
 """
 from . import _lib, deformation, densify, io, knn, losses, optim, parallel, rasterizer, regulation, renderer, sh, synthetic  # noqa: F401
 from .deformation import deform_network  # noqa: F401
-from .renderer import render  # noqa: F401
+from .renderer import render, render_views  # noqa: F401
 from .regulation import compute_regulation  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "deform_network", "render", "compute_regulation", "FusedAdam", "rasterizer", "regulation", "optim", "losses", "densify",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "deform_network", "render", "render_views", "compute_regulation", "FusedAdam", "rasterizer", "regulation", "optim", "losses", "densify",
            "deformation", "renderer", "synthetic", "_lib"]

@@ -69,6 +69,119 @@ class _FusedRenderFunction(torch.autograd.Function):
         return (None, None, None, g_means2D) + grads[:6] + grads[7:]
 
 
+class _FusedRenderViewsFunction(torch.autograd.Function):
+    """The `batch_size` views of one optimizer step (train.py:180-201) behind ONE autograd node: every view's backward accumulates into
+    the SAME gradient arena (first view: the epilogue assigns the per-Gaussian identity paths, later views accumulate), so a step pays
+    one arena allocation / zero fill and no per-parameter `grad += grad` kernels (the per-view graph costs 40 of them per extra view)."""
+
+    @staticmethod
+    def forward(ctx, cfg, times, settings_list, nviews, *tensors):
+        means2D = tensors[:nviews]
+        xyz, scales, rotations, opacity, sh_a, sh_b, aabb = tensors[nviews:nviews + 7]
+        rest = tensors[nviews + 7:]
+        want = any(ctx.needs_input_grad)
+        states, colors, radiis, depths = [], [], [], []
+        for v in range(nviews):
+            st = _deformation.forward_impl(cfg, times[v], xyz, scales, rotations, opacity, sh_a, sh_b, None, aabb, rest, want)
+            color, radii, depth, rstate = _rasterizer.rasterize_forward(settings_list[v], st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None)
+            st.o_xyz = st.o_sh = None
+            states.append((st, rstate))
+            colors.append(color); radiis.append(radii); depths.append(depth)
+        ctx.states, ctx.nviews = states, nviews
+        # the activated outputs each view's backward needs: through save_for_backward (no reference cycle through ctx)
+        ctx.save_for_backward(*[t for st, _ in states for t in (st.o_sc, st.o_rot, st.o_op)])
+        for st, _ in states:
+            st.o_sc = st.o_rot = st.o_op = None
+        radii_all = torch.stack(radiis)
+        ctx.mark_non_differentiable(radii_all)
+        ctx.set_materialize_grads(False)
+        return torch.stack(colors), radii_all, torch.stack(depths)
+
+    @staticmethod
+    def backward(ctx, grad_colors, grad_radii, grad_depths):
+        states, nviews = ctx.states, ctx.nviews
+        st0 = states[0][0]
+        n_in = 4 + nviews + 7 + len(st0.plane_shapes) + len(st0.keep[0][8])
+        if grad_colors is None and grad_depths is None:
+            return (None,) * n_in
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        b = _deformation.backward_prepare(st0, saved[0], saved[1], saved[2], identity_assigned=EPILOGUE_ASSIGN)
+        dev = b.d_xyz.device
+        f = lambda t: None if t is None else t.float().contiguous()
+        g_means2D = []
+        keep = []
+        for v, (st, rstate) in enumerate(states):
+            p = rstate.params
+            P = p.P
+            gc = f(grad_colors[v]) if grad_colors is not None else torch.zeros(3, p.H, p.W, device=dev)
+            gd = f(grad_depths[v]) if grad_depths is not None else None
+            g = _lib.RasterGrads()
+            gm, acc = torch.empty(P, 3, device=dev), torch.empty(P, 16, device=dev)
+            g.dL_dcolor, g.dL_ddepth, g.dL_dmeans2D, g.scratch_acc = _lib.ptr(gc), _lib.ptr(gd), _lib.ptr(gm), _lib.ptr(acc)
+            epi = _lib.RasterDeformEpilogue()
+            epi.activate, epi.Npad = 1, (P + 127) // 128 * 128
+            epi.rot_norm, epi.G = _lib.ptr(st.o_norm), _lib.ptr(b.scratch)
+            epi.d_xyz, epi.d_scales, epi.d_rotations, epi.d_opacity = b.g.d_xyz, b.g.d_scales, b.g.d_rotations, b.g.d_opacity
+            epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
+            epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
+            epi.assign = 1 if (EPILOGUE_ASSIGN and v == 0) else 0        # later views accumulate into what the first one assigned
+            g.deform_epilogue = _lib.ctypes.pointer(epi)
+            _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
+                                         rstate.num_rendered, g))
+            # this view's deformation backward: same output pointers and scratch (stream-ordered reuse), its own saved activations
+            b.g.out_scales, b.g.out_rotations, b.g.out_opacity = _lib.ptr(saved[3 * v]), _lib.ptr(saved[3 * v + 1]), _lib.ptr(saved[3 * v + 2])
+            b.g.rot_norm, b.g.saved = _lib.ptr(st.o_norm), _lib.ptr(st.saved_act)
+            b.g.packed_rows_ready = 1
+            _lib.check(L.fdgs_deform_bwd(_lib.stream_ptr(), st.p, b.g))
+            g_means2D.append(gm)
+            keep.append((gc, gd, acc, epi))
+        cfg, sh = st0.cfg, st0.shapes
+        d_mlp = b.d_mlp
+        for h in range(_lib.NUM_HEADS):
+            if not cfg["head_on"][h]:
+                d_mlp[2 + 4 * h:6 + 4 * h] = [None] * 4
+        return (None, None, None, None, *g_means2D, b.d_xyz, b.d_sc.reshape(sh["scales"]), b.d_rot.reshape(sh["rot"]), b.d_op.reshape(sh["op"]),
+                b.d_sha.reshape(sh["sh_a"]), None if b.d_shb is None else b.d_shb.reshape(sh["sh_b"]), None, *b.d_planes, *d_mlp)
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, stage="fine", cam_type=None):
+    """The views of one optimizer step rendered behind one autograd node: `[render(cam, ...) for cam in viewpoint_cameras]` of the
+    reference's batch loop (train.py:180-198) with the same per-view result dicts, but one gradient arena for the whole step (see
+    _FusedRenderViewsFunction).  Falls back to per-view render() wherever the fused fine stage does not apply."""
+    cams = list(viewpoint_cameras)
+    fusable = (FUSED_BACKWARD and "fine" in stage and isinstance(pc._deformation, _deformation.deform_network)
+               and not pipe.compute_cov3D_python and not pipe.convert_SHs_python and len(cams) > 0)
+    if not fusable:
+        return [render(c, pc, pipe, bg_color, scaling_modifier, None, stage, cam_type) for c in cams]
+    means3D = pc.get_xyz
+    device = means3D.device
+    settings, times = [], []
+    for cam in cams:
+        if cam_type != "PanopticSports":
+            settings.append(GaussianRasterizationSettings(
+                image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+                tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+                viewmatrix=_dev(cam.world_view_transform, device), projmatrix=_dev(cam.full_proj_transform, device),
+                sh_degree=pc.active_sh_degree, campos=_dev(cam.camera_center, device), prefiltered=False, debug=pipe.debug))
+            times.append(float(cam.time))
+        else:
+            settings.append(cam["camera"])
+            times.append(float(cam["time"]))
+    if len({(s_.image_height, s_.image_width) for s_ in settings}) != 1:
+        return [render(c, pc, pipe, bg_color, scaling_modifier, None, stage, cam_type) for c in cams]
+    sinks = [torch.zeros_like(means3D, requires_grad=True) for _ in cams]
+    net = pc._deformation
+    planes, mlp = _deformation._collect(net)
+    dn = net.deformation_net
+    cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W, head_on=_deformation._head_on(dn.args),
+               activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()))
+    colors, radii, depths = _FusedRenderViewsFunction.apply(cfg, times, settings, len(cams), *sinks, means3D, pc._scaling, pc._rotation,
+                                                            pc._opacity, pc._features_dc, pc._features_rest, dn.grid.aabb, *planes, *mlp)
+    return [{"render": colors[v], "viewspace_points": sinks[v], "visibility_filter": radii[v] > 0, "radii": radii[v], "depth": depths[v]}
+            for v in range(len(cams))]
+
+
 def _dev(t, device):
     return t if t.device == device else t.to(device, non_blocking=True)
 

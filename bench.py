@@ -247,6 +247,35 @@ def run(args):
         train = {"iterations_per_s": world * args.steps / dt_tr, "ms_per_iteration": dt_tr / args.steps * 1e3,
                  "includes": "render fwd+bwd, L1 stats, densification statistics, HexPlane regulariser fwd+bwd, FusedAdam step over all 8 parameter groups (lr = 0)",
                  "extra_kernels_ms_per_iteration": extra}
+    # ---- secondary measurement: the views of one optimizer step behind one autograd node (fdgs.render_views; the reference's batch loop,
+    # train.py:180-201, with batch_size = 2 as arguments/dynerf/cook_spinach.py:3 sets it): frames/s with the step's gradient arena shared
+    batched = None
+    if not args.no_train_step:
+        B = 2
+        dimgs = [torch.empty(3, H, W, device=dev) for _ in range(B)]
+
+        def batch_step(i):
+            for p_ in params:
+                p_.grad = None
+            vc = [cams[par.frames_for_rank(len(cams), B * i + v, rank, world)] for v in range(B)]
+            res = fdgs.render_views(vc, pc, pipe, bg, stage="fine")
+            acc.zero_()
+            for v in range(B):
+                img = res[v]["render"]
+                fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / (B * img.numel()), ptr(dimgs[v]), ptr(acc)))
+            torch.autograd.backward([r_["render"] for r_ in res], dimgs)
+
+        for i in range(max(args.warmup // 2, 2)):
+            batch_step(i)
+        par.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = max(args.steps // 2, 1)
+        for i in range(nb):
+            batch_step(i)
+        par.barrier(); torch.cuda.synchronize()
+        dt_b = par.max_over_ranks(time.perf_counter() - t0, dev)
+        batched = {"views_per_step": B, "frames_per_s": world * B * nb / dt_b, "ms_per_step": dt_b / nb * 1e3, "ms_per_frame": dt_b / nb / B * 1e3,
+                   "api": "fdgs.render_views (one autograd node and one gradient arena per optimizer step)"}
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cam_p = cams[args.warmup % len(cams)]
@@ -260,7 +289,7 @@ def run(args):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "src_sha16": lib_sha16(fdgs),
             "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "gaussian_order": args.order, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "train_iteration": train,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "train_iteration": train, "batched_step": batched,
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "timed_regions_ms_per_step": [round(x / args.steps * 1e3, 4) for x in regions], "value_is": "median of the timed regions",
             "frame_hbm": {"algorithmic_bytes": B_frame, "achieved_GBps": B_frame / (dt / args.steps / 1) / 1e9 if world == 1 else None,

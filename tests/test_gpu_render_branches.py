@@ -245,3 +245,34 @@ def test_fused_backward_small_and_ragged_counts_both_epilogue_modes(n, assign, m
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert rel_l2(a[k].cpu().numpy(), b[k].cpu().numpy()) < 2e-5, (k, n, assign)
+
+
+@pytest.mark.parametrize("nviews", [1, 3])
+def test_render_views_equals_per_view_render_with_summed_loss(nviews):
+    """fdgs.render_views: the views of one optimizer step behind one autograd node and one gradient arena, against the reference's
+    loop of render() calls whose losses are summed before one backward (train.py:180-219): identical images / radii / depth, every
+    parameter gradient and every view's viewspace gradient equal to summation noise."""
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    cams = [synthetic.make_camera(160, 120, theta_deg=-60.0 + 70.0 * v, time=0.15 + 0.3 * v).to(dev) for v in range(nviews)]
+    ws = [torch.randn(3, 120, 160, generator=torch.Generator().manual_seed(40 + v)).to(dev) for v in range(nviews)]
+    bg = torch.zeros(3, device=dev)
+    pc = _model(5003, "dynerf_default", seed=12)
+    res_a = fd.render_views(cams, pc, _Pipe(), bg, stage="fine")
+    sum((r["render"] * w).sum() for r, w in zip(res_a, ws)).backward()
+    ga = {k: p.grad.clone() for k, p in pc.named_parameters() if p.grad is not None}
+    va = [r["viewspace_points"].grad.clone() for r in res_a]
+    for p in pc.parameters():
+        p.grad = None
+    res_b = [fd.render(c, pc, _Pipe(), bg, stage="fine") for c in cams]
+    sum((r["render"] * w).sum() for r, w in zip(res_b, ws)).backward()
+    gb = {k: p.grad.clone() for k, p in pc.named_parameters() if p.grad is not None}
+    for ra, rb in zip(res_a, res_b):
+        for key in ("render", "depth", "radii", "visibility_filter"):
+            assert torch.equal(ra[key], rb[key]), key
+    assert set(ga) == set(gb)
+    worst = max((rel_l2(ga[k].cpu().numpy(), gb[k].cpu().numpy()), k) for k in ga)
+    print(f"[{nviews} views] batched node vs per-view graphs: worst gradient rel-L2 {worst[0]:.1e} ({worst[1]})")
+    assert worst[0] < 2e-5
+    for v in range(nviews):
+        assert rel_l2(va[v].cpu().numpy(), res_b[v]["viewspace_points"].grad.cpu().numpy()) < 1e-6
