@@ -66,8 +66,9 @@ class RasterState:
     __slots__ = ("params", "geom", "binning", "img", "num_rendered", "keep")
 
 
-def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp):
-    """Runs stages 1-4 of include/fdgs.h. Returns (color, radii, depth, state)."""
+def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None):
+    """Runs stages 1-4 of include/fdgs.h. Returns (color, radii, depth, state).  `out` = (color [3,H,W], radii [P] int32, depth [1,H,W])
+    buffers to write into (contiguous float32 / int32 on the device), e.g. slices of a batch tensor."""
     L = _lib.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -99,9 +100,12 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     geom = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     check(L.fdgs_img_bytes(W, H, nbytes))
     img = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    radii = torch.empty(P, dtype=torch.int32, device=dev)
-    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-    depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    if out is not None:
+        color, radii, depth = out
+    else:
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     st = stream_ptr()
     check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
     host = _pinned_u32(dev)

@@ -80,22 +80,26 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
         xyz, scales, rotations, opacity, sh_a, sh_b, aabb = tensors[nviews:nviews + 7]
         rest = tensors[nviews + 7:]
         want = any(ctx.needs_input_grad)
-        states, colors, radiis, depths = [], [], [], []
+        dev, P = xyz.device, xyz.shape[0]
+        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+        colors = torch.empty(nviews, 3, H, W, device=dev)          # every view renders straight into its slice
+        radii_all = torch.empty(nviews, P, dtype=torch.int32, device=dev)
+        depths = torch.empty(nviews, 1, H, W, device=dev)
+        states = []
         for v in range(nviews):
             st = _deformation.forward_impl(cfg, times[v], xyz, scales, rotations, opacity, sh_a, sh_b, None, aabb, rest, want)
-            color, radii, depth, rstate = _rasterizer.rasterize_forward(settings_list[v], st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None)
+            _, _, _, rstate = _rasterizer.rasterize_forward(settings_list[v], st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None,
+                                                            out=(colors[v], radii_all[v], depths[v]))
             st.o_xyz = st.o_sh = None
             states.append((st, rstate))
-            colors.append(color); radiis.append(radii); depths.append(depth)
         ctx.states, ctx.nviews = states, nviews
         # the activated outputs each view's backward needs: through save_for_backward (no reference cycle through ctx)
         ctx.save_for_backward(*[t for st, _ in states for t in (st.o_sc, st.o_rot, st.o_op)])
         for st, _ in states:
             st.o_sc = st.o_rot = st.o_op = None
-        radii_all = torch.stack(radiis)
         ctx.mark_non_differentiable(radii_all)
         ctx.set_materialize_grads(False)
-        return torch.stack(colors), radii_all, torch.stack(depths)
+        return colors, radii_all, depths
 
     @staticmethod
     def backward(ctx, grad_colors, grad_radii, grad_depths):
