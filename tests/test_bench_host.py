@@ -1,0 +1,46 @@
+"""Host-side logic of bench.py that needs no GPU: counter artefacts are only quoted for the workload and the kernel sources they were
+collected with, and the two places that compute the source hash agree."""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_source_hash_agrees_between_bench_and_pmc_tool():
+    bench = _load("bench_mod", os.path.join(ROOT, "bench.py"))
+    tool = _load("pmc_traffic_mod", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+    assert bench.lib_sha16(None) == tool.src_sha16() and len(tool.src_sha16()) == 16
+
+
+def test_pmc_traffic_is_refused_for_other_workloads_and_builds(tmp_path, monkeypatch):
+    bench = _load("bench_mod2", os.path.join(ROOT, "bench.py"))
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    art = {"_workload": "cfg4_dynerf_300k_1352x1014", "_src_sha16": "abc", "deform_bwd_data": {"FETCH_SIZE_KB_per_launch": 1000.0, "WRITE_SIZE_KB_per_launch": 500.0}}
+    json.dump(art, open(prof / "r99_pmc_traffic_cfg4.json", "w"))
+    ok = bench.pmc_traffic("deform_bwd_data", "cfg4_dynerf_300k_1352x1014", "abc")
+    assert ok["traffic"] == (2 * 1000.0 + 500.0) * 1024 and ok["traffic_source"].endswith("r99_pmc_traffic_cfg4.json")
+    other_wl = bench.pmc_traffic("deform_bwd_data", "cfg5_stress_2M_2048x2048", "abc")
+    assert other_wl["traffic"] is None and "workload" in other_wl["traffic_refused"]
+    other_build = bench.pmc_traffic("deform_bwd_data", "cfg4_dynerf_300k_1352x1014", "zzz")
+    assert other_build["traffic"] is None and "other build" in other_build["traffic_refused"]
+    missing = bench.pmc_traffic("render_bwd", "cfg4_dynerf_300k_1352x1014", "abc")
+    assert missing["traffic"] is None and "not profiled" in missing["traffic_source"]
+
+
+def test_committed_artefact_matches_the_committed_sources():
+    """The newest per-workload artefact under profiles/ for the bench workload was collected with the kernel sources in the tree (if
+    this fails after a kernel edit: re-collect with tools/gpu_round.sh PMC=1, or bench.py will report traffic = null)."""
+    bench = _load("bench_mod3", os.path.join(ROOT, "bench.py"))
+    r = bench.pmc_traffic("deform_bwd_data", "cfg4_dynerf_300k_1352x1014", bench.lib_sha16(None))
+    assert r["traffic"] is not None, r
