@@ -55,7 +55,7 @@ class DeformGrads(Structure):
                 ("d_shs_dc", c_void_p), ("d_shs_rest", c_void_p), ("d_planes", (c_void_p * 6) * MAX_LEVELS),
                 ("d_w0", c_void_p), ("d_b0", c_void_p), ("d_w1", c_void_p * NUM_HEADS), ("d_b1", c_void_p * NUM_HEADS),
                 ("d_w2", c_void_p * NUM_HEADS), ("d_b2", c_void_p * NUM_HEADS), ("scratch", c_void_p), ("saved", c_void_p),
-                ("packed_rows_ready", c_int)]
+                ("packed_rows_ready", c_int), ("spatially_ordered", c_int)]
 
 
 class RegPlane(Structure):

@@ -2382,7 +2382,9 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     if (any_plane) {
         // matrix-core splat (default whenever one frame time is shared by all Gaussians, i.e. on the render() path): the
         // fixed LDS part is the dv tile, coordinates, descriptors; the time rows get what is left of the 160 KB
-        const bool use_mfma = !p->time && tunable("FDGS_D4_MFMA", 1);
+        // FDGS_D4_MFMA = 1 / 0 forces a kernel (A/B, tests); otherwise the caller's order hint decides
+        const int d4_env = tunable("FDGS_D4_MFMA", -1);
+        const bool use_mfma = !p->time && (d4_env >= 0 ? d4_env != 0 : g->spatially_ordered != 0);
         // workgroup shape of the splat: 8 waves, one workgroup per CU (default); FDGS_D4_WAVES=4 selects 4-wave workgroups with half
         // the chunk, two per CU where the LDS allows -- measured equal on BASELINE config 4 (0.331 vs 0.322 ms: overlapping one
         // workgroup's sampling with the other's matrix-core phase buys what the smaller chunks lose in merging), kept for A/B

@@ -167,12 +167,13 @@ def _collect(net):
     return planes, mlp
 
 
-def deform(net, xyz, scales, rotations, opacity, shs=None, shs_dc=None, shs_rest=None, time=None, activate=False):
+def deform(net, xyz, scales, rotations, opacity, shs=None, shs_dc=None, shs_rest=None, time=None, activate=False, ordered=None):
     """Runs the fused deformation.  Either `shs` ([N,16,3]) or the pair (shs_dc [N,1,3], shs_rest [N,15,3]) is given
     (the pair skips the torch.cat of GaussianModel.get_features, scene/gaussian_model.py:121-124).  `time` is a python
     float (one frame time for all Gaussians, as render() uses it) or a [N,1] tensor.
     Returns (means3D, scales, rotations, opacity, shs [N,16,3]); with activate=True scales/rotations/opacity have had
-    exp / normalize / sigmoid applied (gaussian_renderer/__init__.py:97-99)."""
+    exp / normalize / sigmoid applied (gaussian_renderer/__init__.py:97-99).  `ordered`: the rows are spatial neighbours (None: measured
+    once per position tensor, see spatial_order_hint) -- selects the plane-gradient kernel, never the result."""
     planes, mlp = _collect(net)
     dn = net.deformation_net
     cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
@@ -180,7 +181,8 @@ def deform(net, xyz, scales, rotations, opacity, shs=None, shs_dc=None, shs_rest
                # grad mode is read HERE: inside autograd.Function.forward it is always off, and needs_input_grad stays True
                # under torch.no_grad() -- evaluation frames (render.py, training_report) must not allocate ~3.2 KB per
                # Gaussian of saved activations nor take the slower saving forward
-               save=bool(SAVE_ACTIVATIONS and torch.is_grad_enabled()))
+               save=bool(SAVE_ACTIVATIONS and torch.is_grad_enabled()),
+               ordered=spatial_order_hint(xyz) if ordered is None else bool(ordered))
     if isinstance(time, torch.Tensor):
         t_tensor, t_scalar = time, 0.0
     else:
@@ -243,6 +245,30 @@ def _aabb_to_host(aabb):
     vals = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
     _aabb_cache[0], _aabb_cache[1], _aabb_cache[2] = weakref.ref(aabb), key, vals
     return vals
+
+
+_order_cache = [None, None, False]   # (weakref to the position tensor object, its shape, ordered?)
+
+
+def spatial_order_hint(xyz):
+    """True when consecutive rows of `xyz` are spatial neighbours (the set was ordered along a space-filling curve, e.g. by
+    fdgs.densify.spatial_reorder).  Measured, not declared: mean distance between consecutive positions against the bounding-box
+    diagonal (random order: ~0.38; Hilbert order at 10^4..10^6 points: < 0.05), once per tensor OBJECT -- the train loop only creates
+    a new position Parameter when the set is rebuilt (densify / prune / reorder), optimizer steps move it in place and do not change
+    the order.  Decides only which of two equivalent plane-gradient kernels runs (fdgs_deform_grads::spatially_ordered)."""
+    import weakref
+    ref, shape, val = _order_cache
+    if ref is not None and ref() is xyz and shape == tuple(xyz.shape):
+        return val
+    val = False
+    if xyz.shape[0] >= 256:
+        with torch.no_grad():
+            x = xyz.detach()
+            step = (x[1:] - x[:-1]).norm(dim=1).mean()
+            diag = (x.max(0).values - x.min(0).values).norm().clamp_min(1e-20)
+            val = bool((step / diag).item() < 0.1)
+    _order_cache[0], _order_cache[1], _order_cache[2] = weakref.ref(xyz), tuple(xyz.shape), val
+    return val
 
 
 class _FwdState:
@@ -346,6 +372,7 @@ def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False):
     b.scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     g.scratch = ptr(b.scratch)
     g.saved = ptr(st.saved_act)
+    g.spatially_ordered = 1 if cfg.get("ordered") else 0
     b.g = g
     return b
 

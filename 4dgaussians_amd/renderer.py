@@ -179,7 +179,8 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, st
     planes, mlp = _deformation._collect(net)
     dn = net.deformation_net
     cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W, head_on=_deformation._head_on(dn.args),
-               activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()))
+               activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()),
+               ordered=_deformation.spatial_order_hint(pc._xyz))
     colors, radii, depths = _FusedRenderViewsFunction.apply(cfg, times, settings, len(cams), *sinks, means3D, pc._scaling, pc._rotation,
                                                             pc._opacity, pc._features_dc, pc._features_rest, dn.grid.aabb, *planes, *mlp)
     return [{"render": colors[v], "viewspace_points": sinks[v], "visibility_filter": radii[v] > 0, "radii": radii[v], "depth": depths[v]}
@@ -234,7 +235,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             dn = net.deformation_net
             cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
                        head_on=_deformation._head_on(dn.args), activate=True,
-                       save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()))
+                       save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()),
+                       ordered=_deformation.spatial_order_hint(pc._xyz))
             rendered_image, radii, depth = _FusedRenderFunction.apply(
                 cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
                 dn.grid.aabb, *planes, *mlp)

@@ -438,3 +438,16 @@ def test_plane_grad_mfma_time_rows_that_do_not_fit_lds(rows_kb, monkeypatch):
     b, _ = _plane_grads("dynerf_default", 6000, "hilbert", 0.61, False, monkeypatch)
     errs = [rel_l2(x.numpy(), y.numpy()) for x, y in zip(a, b)]
     assert errs[0] < 1e-5 and max(errs[1:]) < 2e-5
+
+
+def test_spatial_order_hint_selects_the_plane_gradient_kernel_not_the_result():
+    """The order hint is measured from the positions (once per tensor object) and only chooses between two equivalent kernels."""
+    fd = _fdgs()
+    dev = torch.device("cuda:0")
+    g = synthetic.make_gaussians(20000, seed=3)
+    x = g["xyz"].to(dev)
+    assert fd.deformation.spatial_order_hint(x) is False
+    keys = fd.densify.hilbert_keys(x)
+    xs = x[torch.argsort(keys)].contiguous()
+    assert fd.deformation.spatial_order_hint(xs) is True
+    assert fd.deformation.spatial_order_hint(xs[:100].contiguous()) is False        # too few rows to say
