@@ -85,3 +85,20 @@ def test_hilbert_chunks_fit_the_texel_window():
     pix = ((x - lo) / (hi - lo) * 63).floor().long()[: 100_000 // 128 * 128].reshape(-1, 128, 3)
     inside = ((pix - pix.min(1, keepdim=True).values) <= 14).all(2).float().mean()
     assert float(inside) > 0.97
+
+
+def test_spatial_order_hint_is_measured_from_the_positions():
+    """deformation.spatial_order_hint (host side, any device): random order -> False, curve order -> True, cached per tensor object."""
+    syn = fdgs.synthetic
+    x = syn.make_gaussians(20_000, seed=4)["xyz"]
+    hint = fdgs.deformation.spatial_order_hint
+    assert hint(x) is False
+    xs = x[torch.argsort(D.hilbert_keys(x))].contiguous()
+    assert hint(xs) is True and hint(xs) is True
+    xm = x[torch.argsort(D.morton_keys(x))].contiguous()
+    assert hint(xm) is True
+    assert hint(xs[:50].contiguous()) is False          # too few rows to tell: the conservative answer
+    # four concatenated curve-ordered runs (what densify leaves behind: kept originals, clones, first and second children) still count
+    # as ordered: only the three run boundaries jump
+    runs = torch.cat([xs[0::4], xs[1::4], xs[2::4], xs[3::4]])
+    assert hint(runs.contiguous()) is True
