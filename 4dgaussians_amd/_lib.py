@@ -23,7 +23,7 @@ class RasterParams(Structure):
 class RasterDeformEpilogue(Structure):
     _fields_ = [("activate", c_int), ("Npad", c_int), ("rot_norm", c_void_p), ("G", c_void_p), ("d_xyz", c_void_p),
                 ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p), ("d_shs_dc", c_void_p),
-                ("d_shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int), ("assign", c_int)]
+                ("d_shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int), ("assign", c_int), ("tile_flags", c_int)]
 
 
 class RasterGrads(Structure):
@@ -106,6 +106,7 @@ SYMBOLS = {
     "fdgs_deform_fwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformOut)]),
     "fdgs_deform_bwd_scratch_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),
+    "fdgs_deform_bwd_live_tiles": (c_int, [c_void_p, POINTER(DeformParams), c_void_p, POINTER(c_uint32)]),
     "fdgs_l1_stats": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "fdgs_image_loss_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdgs_image_loss_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),

@@ -373,7 +373,11 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     GeomLayout gl = geom_layout(p->P);
     // the total was accumulated by preprocess: start its read-back now, sort while it is in flight
     // one event per host thread, created on first use and kept (the ABI contract is one host thread per stream)
-    static thread_local hipEvent_t ev = nullptr;
+    // (per DEVICE: an event belongs to the device that was current when it was created; a thread that later renders on another GPU
+    // gets its own)
+    static thread_local hipEvent_t evs[FDGS_MAX_DEVICES] = {};
+    const int dev_ = current_device_slot();
+    hipEvent_t& ev = evs[dev_];
     if (!ev) FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
     FDGS_HIP_CHECK(hipEventRecord(ev, stream));

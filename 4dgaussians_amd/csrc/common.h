@@ -56,6 +56,14 @@ inline int tunable(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// per-device host-side state (cached events, "function attribute already raised" flags) is indexed by the current device
+constexpr int FDGS_MAX_DEVICES = 64;
+inline int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % FDGS_MAX_DEVICES;
+}
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -62,6 +62,8 @@ __device__ __forceinline__ int frow(int t, int r, int h) { return t * 32 + (r & 
 __host__ __device__ __forceinline__ int head_k(int hd) { return hd == 0 ? 3 : hd == 1 ? 3 : hd == 2 ? 4 : hd == 3 ? 1 : 48; }
 __host__ __device__ __forceinline__ int head_off(int hd) { return hd == 0 ? 0 : hd == 1 ? 3 : hd == 2 ? 6 : hd == 3 ? 10 : 16; }
 constexpr int GCOLS = 64;
+// first row of a head's k output rows in arrays that stack the five heads (3 + 3 + 4 + 1 + 48 = 59 rows)
+__host__ __device__ __forceinline__ int head_row0(int hd) { return hd == 0 ? 0 : hd == 1 ? 3 : hd == 2 ? 6 : hd == 3 ? 10 : 11; }
 
 // ------------------------------------------------------------------------------------------------ HexPlane gather
 struct AxisSample {
@@ -481,8 +483,23 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     constexpr int PD1 = WT == 4 ? FDGS_D1_PD1 : FwdPD<WT>::L1, PD2 = FwdPD<WT>::L2;
     const fdgs_deform_params& p = d.p;
     const bool tunable_small = d.small_heads != 0;
-    __shared__ __attribute__((aligned(16))) float fwd_lds[4 * 32 * (WT * 32 + 4)];   // staging tiles of the saved activations
-    float* my_tile = fwd_lds + (threadIdx.x >> 6) * 32 * (WT * 32 + 4);
+    // LDS: the four waves' staging tiles of the saved activations + the second-layer weights of all heads (59 rows, padded row
+    // stride: rows i = 0..3 of a 4x4x1 product and the two lane halves fall into distinct banks).  The second layers are short
+    // products (64 MFMAs of 8 cycles for a k <= 4 head) whose operand ring cannot cover an L2 round trip: read from LDS they lose
+    // the ~2 k cycles per head that the in-kernel cycle profile charged to "L2" beyond its MFMA time.
+    constexpr int LDW = WT * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float fwd_lds[4 * 32 * LDW + 59 * LDW];
+    float* my_tile = fwd_lds + (threadIdx.x >> 6) * 32 * LDW;
+    float* w2lds = fwd_lds + 4 * 32 * LDW;
+    for (int hd_ = 0; hd_ < FDGS_NUM_HEADS; hd_++) {
+        if (!p.head_on[hd_]) continue;
+        const int k_ = head_k(hd_), r0_ = head_row0(hd_);
+        for (int i = threadIdx.x; i < k_ * (WT * 8); i += 256) {
+            const int r = i / (WT * 8), c4 = i - r * (WT * 8);
+            *reinterpret_cast<float4*>(w2lds + (r0_ + r) * LDW + 4 * c4) = reinterpret_cast<const float4*>(p.w2[hd_])[i];
+        }
+    }
+    __syncthreads();
     constexpr int FT = (FCH + 3) / 4;
     const int lane = threadIdx.x & 63, g0 = lane & 31, h0 = lane >> 5;
     // Every wave walks its own tiles (32 Gaussians each): nothing in the body synchronises the workgroup, so with
@@ -625,15 +642,16 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         const int k = head_k(hd);
         DenseIL<WT, 1, false, PD2> L2, L2b;
         const bool small = k <= 4 && tunable_small;
-        if (small) L2.setup4(p.w2[hd], p.b2[hd], W, k, g, h);
-        else L2.setup(p.w2[hd], p.b2[hd], W, k < 32 ? k : 32, g, h);
+        const float* w2h = w2lds + head_row0(hd) * LDW;
+        if (small) L2.setup4(w2h, p.b2[hd], LDW, k, g, h);
+        else L2.setup(w2h, p.b2[hd], LDW, k < 32 ? k : 32, g, h);
         L2.preload();
         f32x16 h1[WT];
         L1.run(hid, h1, h, drain_piece);
         D1_TICK(3);
         relu_inplace<WT>(h1);
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
-        if (k > 32) { L2b.setup(p.w2[hd] + (size_t)32 * W, p.b2[hd] + 32, W, k - 32, g, h); L2b.preload(); }
+        if (k > 32) { L2b.setup(w2h + 32 * LDW, p.b2[hd] + 32, LDW, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head(p.head_on, hd);
         if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
         f32x16 o0 = zero16(), o1 = zero16();
@@ -670,6 +688,7 @@ struct PrepArgs {
     const float *g_xyz, *g_scales, *g_rot, *g_opacity, *g_shs, *out_scales, *out_rot, *out_opacity, *rot_norm;
     float *d_xyz, *d_scales, *d_rot, *d_opacity, *d_shs_dc, *d_shs_rest;
     float* G;
+    uint32_t* tile_live;   // [Npad/32]: 1 when any packed row of the 32-row tile is non-zero
 };
 // One wave per 64 consecutive Gaussians.  Every array is written as one contiguous block per wave (G: 16 KB, d_shs:
 // 12 KB, d_xyz: 768 B ...) by staging the per-Gaussian rows in LDS and walking the block linearly, lane-consecutive:
@@ -731,6 +750,22 @@ __global__ void __launch_bounds__(256) deform_bwd_prep_kernel(PrepArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    // ---- per 32-row tile: does any row carry a gradient?  (the backward kernels skip tiles of all-zero rows)
+    {
+        bool nz = false;
+#pragma unroll
+        for (int i = 0; i < 11; i++) nz = nz || (row[i] != 0.f);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const float4 x = reinterpret_cast<const float4*>(sh)[lane * 12 + j];
+            nz = nz || x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f;
+        }
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) {
+            a.tile_live[n0 >> 5] = (uint32_t)(m & 0xffffffffull) != 0u ? 1u : 0u;
+            a.tile_live[(n0 >> 5) + 1] = (uint32_t)(m >> 32) != 0u ? 1u : 0u;
+        }
+    }
     // ---- packed gradient rows G[n][64] = [small 16 | shs 48] (padded rows n >= N are zero)
     {
         float4* G4 = reinterpret_cast<float4*>(a.G + (size_t)n0 * GCOLS);
@@ -786,9 +821,91 @@ __global__ void __launch_bounds__(256) deform_bwd_prep_kernel(PrepArgs a) {
     if (a.d_opacity && lane < nvalid) a.d_opacity[n] += small[lane * 16 + 10];
 }
 
+// ------------------------------------------------------------------------------------------------ live-tile lists
+// Lists written by an EARLIER kernel are read through the constant address space: a wave-uniform index then gives a scalar
+// (s_load) read.  Through a plain global pointer the compiler must assume the kernel's own stores may alias the list and falls back
+// to a vector load + readfirstlane -- which joins the in-order vmcnt queue behind the prefetched activation rows and drags the
+// derived addresses into vector registers.
+typedef const uint32_t __attribute__((address_space(4))) * const_u32p;
+__device__ __forceinline__ const_u32p as_const(const uint32_t* p) { return (const_u32p)(unsigned long long)p; }
+
+// The rasterizer hands zero gradient rows to every Gaussian that is culled, off-screen or fully occluded (on the bench scene:
+// 88 % of them, profiles/r03a_zero_gradient_rows.jsonl), and a zero row adds exactly zero to every sum the backward forms.
+// With the set in spatial order such Gaussians are contiguous, so whole 32-row tiles are zero: the packing stage
+// (deform_bwd_prep_kernel, or fdgs_raster_bwd's epilogue) leaves one flag per tile behind, this kernel turns the flags into
+//   live[]   : ascending indices of the tiles with a non-zero row, padded to a multiple of 4 with a zero tile (D2's workgroups take
+//              four tiles at a time and meet at barriers),
+//   chunks[] : ascending indices of the plane-gradient chunks (tpc tiles each) that contain a live tile,
+//   counters : { live tiles, live tiles padded, live chunks, tiles },
+// and D2 / D3 / D4 walk the lists instead of 0 .. Npad/32.  One workgroup; ~5 us.  skip = 0 lists every tile (A/B, FDGS_SKIP_DEAD=0).
+struct CompactArgs {
+    const uint32_t* flags; uint32_t* live; uint32_t* chunks; uint32_t* counters;
+    int ntiles, tpc, skip;
+};
+__global__ void __launch_bounds__(1024) tile_compact_kernel(CompactArgs a) {
+    __shared__ uint32_t wl[16], wc[16];
+    __shared__ uint32_t first_dead;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) first_dead = 0xffffffffu;
+    __syncthreads();
+    int span = (a.ntiles + 1023) / 1024;
+    span = (span + 3) & ~3;                              // (ntiles and span are multiples of 4: aligned uint4 reads, whole chunks)
+    const int b = t * span, e = b + span < a.ntiles ? b + span : a.ntiles;
+    uint32_t nl = 0, nc = 0, fd = 0xffffffffu;
+    for (int i = b; i < e; i += 4) {
+        uint4 f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
+        if (!a.skip) f = make_uint4(1u, 1u, 1u, 1u);
+        const uint32_t fv[4] = {f.x != 0u, f.y != 0u, f.z != 0u, f.w != 0u};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            nl += fv[j];
+            if (!fv[j] && fd == 0xffffffffu) fd = (uint32_t)(i + j);
+        }
+        if (a.tpc == 4) nc += (fv[0] | fv[1] | fv[2] | fv[3]);
+        else if (a.tpc == 2) nc += (fv[0] | fv[1]) + (fv[2] | fv[3]);
+        else nc += fv[0] + fv[1] + fv[2] + fv[3];
+    }
+    if (fd != 0xffffffffu) atomicMin(&first_dead, fd);
+    uint32_t il = nl, ic = nc;       // inclusive scans inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ul = __shfl_up(il, o, 64), uc = __shfl_up(ic, o, 64);
+        if (lane >= o) { il += ul; ic += uc; }
+    }
+    if (lane == 63) { wl[wv] = il; wc[wv] = ic; }
+    __syncthreads();
+    uint32_t pl = il - nl, pc = ic - nc, tl = 0, tc = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        if (w < wv) { pl += wl[w]; pc += wc[w]; }
+        tl += wl[w]; tc += wc[w];
+    }
+    for (int i = b; i < e; i += 4) {
+        uint4 f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
+        if (!a.skip) f = make_uint4(1u, 1u, 1u, 1u);
+        const uint32_t fv[4] = {f.x != 0u, f.y != 0u, f.z != 0u, f.w != 0u};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (fv[j]) a.live[pl++] = (uint32_t)(i + j);
+        if (a.tpc == 4) { if (fv[0] | fv[1] | fv[2] | fv[3]) a.chunks[pc++] = (uint32_t)(i >> 2); }
+        else if (a.tpc == 2) { if (fv[0] | fv[1]) a.chunks[pc++] = (uint32_t)(i >> 1); if (fv[2] | fv[3]) a.chunks[pc++] = (uint32_t)((i >> 1) + 1); }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (fv[j]) a.chunks[pc++] = (uint32_t)(i + j);
+        }
+    }
+    if (t == 0) {
+        const uint32_t n4 = (tl + 3u) & ~3u;
+        // (tl % 4 != 0 implies a dead tile exists, because ntiles % 4 == 0)
+        for (uint32_t k = tl; k < n4; k++) a.live[k] = first_dead;
+        a.counters[0] = tl; a.counters[1] = n4; a.counters[2] = tc; a.counters[3] = (uint32_t)a.ntiles;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ D2 backward-data
 struct BwdScratch {
     float *G, *DH1, *DHID, *RH, *FEAT, *DFEAT;
+    uint32_t *tile_live, *live, *chunks, *counters;   // per-tile non-zero flags and the lists tile_compact_kernel builds from them
     int Npad;
 };
 struct BwdDev {
@@ -823,8 +940,6 @@ struct BwdLds {
     static constexpr int ACC_W = KSUM * W;
     static constexpr int TOTAL = 4 * TILE_FLOATS + ACC_W + 64;
 };
-__host__ __device__ __forceinline__ int head_row0(int hd) { return hd == 0 ? 0 : hd == 1 ? 3 : hd == 2 ? 6 : hd == 3 ? 10 : 11; }
-
 template <int NCH, int GQ>
 __device__ __forceinline__ void small_dw2_steps(f32x4* acc, float sa0, float sa1, const float* lds, int stride, int lane) {
     if constexpr (GQ < 32) {
@@ -880,11 +995,19 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #define FDGS_TV_DECL(j) float4 tv##j = make_float4(0.f, 0.f, 0.f, 0.f);
     FDGS_TV_LIST(FDGS_TV_DECL)
     bool tv_loaded = false;   // SAVED: the first head's relu(h1) tile of this tile was requested during the previous tile
-    for (int tile = blockIdx.x * 4 + wave; tile < d.ntiles; tile += gridDim.x * 4) {
+    // the tiles to process: the live list (tiles with a non-zero gradient row, padded to whole groups of four)
+    const const_u32p live_list = as_const(d.s.live);
+    const int nlive4 = (int)as_const(d.s.counters)[1];
+    const int it_stride = gridDim.x * 4;
+    // (list indices are made wave-uniform BEFORE they address the list: scalar loads.  As vector loads they would join the in-order
+    // vmcnt queue behind the prefetched activation rows and every read of the list would wait for those.)
+    for (int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave); it < nlive4; it += it_stride) {
         // opaque per-iteration copies of the lane coordinates: keeps the (hundreds of) loop-invariant weight addresses
         // from being hoisted out of the tile loop and held in registers across it
         int g = g0, h = h0;
         asm volatile("" : "+v"(g), "+v"(h));
+        const int tile = (int)live_list[it];
+        const int tile_next = it + it_stride < nlive4 ? (int)live_list[it + it_stride] : -1;
         const int n0 = tile * 32;  // first Gaussian of this wave's tile (rows < Npad always exist in scratch)
         const int n_row = n0 + g;
         const int n = n_row < p.N ? n_row : p.N - 1;
@@ -944,8 +1067,8 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 int nx = next_head(p.head_on, cur_hd);
                 int nn0 = n0;
                 const bool wrap = nx >= FDGS_NUM_HEADS;
-                if (wrap) { nx = next_head(p.head_on, -1); nn0 = n0 + gridDim.x * 4 * 32; }
-                const bool have = nn0 < d.ntiles * 32;
+                if (wrap) { nx = next_head(p.head_on, -1); nn0 = tile_next * 32; }
+                const bool have = !wrap || tile_next >= 0;
                 tv_loaded = have && wrap;   // "this wave's next tile finds its first rows already requested"
                 if (have) {
                     const float4* tsrc = reinterpret_cast<const float4*>(d.sv_h1 + ((size_t)d.head_slot[nx] * d.s.Npad + nn0) * W);
@@ -1060,23 +1183,33 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 D2_TICK(4);
                 __syncthreads();                                   // all four tiles of the workgroup are written
                 D2_TICK(1);
-                const int nwg0 = (tile - wave) * 32;               // first Gaussian of the workgroup's four tiles
+                // first Gaussians of the workgroup's four tiles (entries it - wave .. + 3 of the live list)
+                int wgn0[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) wgn0[c] = (int)live_list[(it & ~3) + c] * 32;
 #pragma unroll
                 for (int j = 0; j < NU; j++) {
                     const int ot2 = WT == 4 ? j : (wave >> 1), tb = WT == 4 ? wave : (wave & 1);
                     const int o = ot2 * 32 + g;
-                    const float* gp = d.s.G + (size_t)(nwg0 + h) * GCOLS + off + o;
+                    // (a uniform 64-bit base per tile + ONE 32-bit lane offset for all tiles and steps: SGPR-base addressing.  Written as
+                    // `gp[(wgn0[c] + 2 s) * GCOLS]` the 64 requests took a 64-bit vector address each: +300 bytes of spills per lane,
+                    // and the spill reloads wait in the in-order vmcnt queue behind the prefetched activation rows)
+                    const uint32_t gvo = (uint32_t)((h * GCOLS + off + o) * 4);
+                    auto gld = [&](int c, int s) {
+                        const char* base = reinterpret_cast<const char*>(d.s.G) + (size_t)wgn0[c] * (GCOLS * 4);
+                        return *reinterpret_cast<const float*>(base + (gvo + (uint32_t)(2 * s * GCOLS * 4)));
+                    };
                     const float* bp = lds_all + tb * 32 + g;
                     float gq[2][16];
                     f32x16 accS = zero16();
                     float asumS = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 16; s++) gq[0][s] = gp[(size_t)2 * s * GCOLS];
+                    for (int s = 0; s < 16; s++) gq[0][s] = gld(0, s);
 #pragma unroll
                     for (int c = 0; c < 4; c++) {                  // 4 chunks of 16 k-steps = the 4 tiles (32 Gaussians each)
                         if (c + 1 < 4) {
 #pragma unroll
-                            for (int s = 0; s < 16; s++) gq[(c + 1) & 1][s] = gp[(size_t)(32 * (c + 1) + 2 * s) * GCOLS];
+                            for (int s = 0; s < 16; s++) gq[(c + 1) & 1][s] = gld(c + 1, s);
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1247,7 +1380,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             const float v = accW2[row0 * W + i];
             if (v != 0.f) atomicAdd(&d.d_w2[hd][i], v);
         }
-        if ((int)threadIdx.x < k) atomicAdd(&d.d_b2[hd][threadIdx.x], accB2[row0 + threadIdx.x]);
+        if ((int)threadIdx.x < k && accB2[row0 + threadIdx.x] != 0.f) atomicAdd(&d.d_b2[hd][threadIdx.x], accB2[row0 + threadIdx.x]);
     }
 }
 
@@ -1262,20 +1395,25 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 struct WgradJob {
     const float* DY; const float* X; float* dW; float* db;
     int ldx, ncols, ldw;
-    int first_block, nblocks, chunk;   // workgroups [first_block, first_block + nblocks) each take `chunk` Gaussians
+    int first_block, nblocks;   // workgroups [first_block, first_block + nblocks) share the live tiles of this job evenly
 };
 struct WgradArgs {
     WgradJob job[FDGS_NUM_HEADS + 1];
     int njobs, Npad, W;
+    const uint32_t* live;       // live-tile list (tile_compact_kernel)
+    const uint32_t* counters;   // [1] = entries of the list
 };
-constexpr int WG_PD = 6;
 
 // COLS_IL: X has exactly W columns, column mapping interleaved (vector loads); else tile mapping c = 32*b + j with
 // CT = ceil(ncols/32) dword loads per k-step (the small trunk product, ncols = C*L).
-// PD = depth of the operand ring in k-steps: the narrow trunk products run only CT MFMAs per step, so they need a deeper
+// PD (8 or 16) = depth of the operand ring in k-steps: the narrow trunk products run only CT MFMAs per step, so they need a deeper
 // ring than the square head products to cover the same memory latency.
+// The wave walks the tiles [t_begin, t_end) of the LIVE list: a tile is 32 consecutive Gaussians = 16 k-steps, tiles need not be
+// adjacent in memory (tiles whose gradient rows are all zero were dropped from the list: their products are exactly zero).
 template <int WT, int CT, bool COLS_IL, int PD>
-__device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin, int n_end, float* ldsW, float* ldsB, int g, int h, int wave) {
+__device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, const_u32p live, int t_begin, int t_end, float* ldsW, float* ldsB,
+                                           int g, int h, int wave) {
+    static_assert(16 % PD == 0, "the ring must divide a tile's 16 k-steps");
     constexpr int BV = COLS_IL ? WT : 1, NB = COLS_IL ? 1 : CT;
     f32x16 acc[WT][CT];
 #pragma unroll
@@ -1285,29 +1423,19 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
     float asum[WT];
 #pragma unroll
     for (int a = 0; a < WT; a++) asum[a] = 0.f;
-    const float* ap = J.DY + (size_t)(n_begin + h) * W + WT * g;
+    const float* ap = J.DY + (size_t)h * W + WT * g;          // + row * W, row = first Gaussian of the k-step (even)
     const float* bp[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         int col = COLS_IL ? WT * g : 32 * b + g;
         col = col < J.ncols ? col : J.ncols - 1;
-        bp[b] = J.X + (size_t)(n_begin + h) * J.ldx + col;
+        bp[b] = J.X + (size_t)h * J.ldx + col;
     }
-    const int nsteps = (n_end - n_begin) >> 1;   // chunk lengths are even; 0 for a wave without work (it still joins the reduction)
     AVec<WT> abuf[PD];
     AVec<BV> bbuf[PD][NB];
-#pragma unroll
-    for (int s = 0; s < PD; s++) {
-        if (nsteps == 0) break;
-        const int ss = s < nsteps ? s : 0;
-        abuf[s] = ldv<WT>(ap + (size_t)ss * 2 * W);
-#pragma unroll
-        for (int b = 0; b < NB; b++) bbuf[s][b] = ldv<BV>(bp[b] + (size_t)ss * 2 * J.ldx);
-    }
-    // Full groups of PD steps without any control flow inside: slot u is consumed, THEN refilled in place with step
-    // s + PD.  (The first form copied the slot, refilled it and then ran the MFMAs under `if (s < nsteps)`; the register
-    // copies at the loop back-edge and the per-step branches made the wait-count pass put `vmcnt(0)` in front of the last
-    // MFMAs of EVERY step, i.e. each step waited for the loads it had just issued: 57 % MFMA utilisation, rocprofv3 r01h.)
+    // slot u is consumed, THEN refilled in place with the step PD ahead; no control flow inside a tile.  (A first form copied the
+    // slot, refilled it and then ran the MFMAs under `if (s < nsteps)`; the register copies at the loop back-edge and the per-step
+    // branches made the wait-count pass put `vmcnt(0)` in front of the last MFMAs of EVERY step: 57 % MFMA utilisation, rocprofv3 r01h.)
     auto consume = [&](int u) {
 #pragma unroll
         for (int a = 0; a < WT; a++) asum[a] += abuf[u].v[a];
@@ -1317,25 +1445,32 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, int n_begin
             for (int b = 0; b < CT; b++)
                 acc[a][b] = mfma32(abuf[u].v[a], COLS_IL ? bbuf[u][0].v[b] : bbuf[u][b].v[0], acc[a][b]);
     };
-    const int ngroups = nsteps / PD;
-    for (int gi = 0; gi < ngroups; gi++) {
+    auto fill = [&](int u, int row) {
+        abuf[u] = ldv<WT>(ap + (size_t)row * W);
 #pragma unroll
-        for (int u = 0; u < PD; u++) {
-            consume(u);
-            __builtin_amdgcn_sched_barrier(0);
-            int sn = (gi + 1) * PD + u;
-            sn = sn < nsteps ? sn : nsteps - 1;   // past the end: harmless re-load of a valid row, never consumed
-            abuf[u] = ldv<WT>(ap + (size_t)sn * 2 * W);
+        for (int b = 0; b < NB; b++) bbuf[u][b] = ldv<BV>(bp[b] + (size_t)row * J.ldx);
+    };
+    if (t_end > t_begin) {
+        auto tile_row = [&](int ti) { return (int)live[ti < t_end ? ti : t_end - 1] * 32; };      // (uniform index: scalar load)
+        int cur = tile_row(t_begin), nxt = tile_row(t_begin + 1);
 #pragma unroll
-            for (int b = 0; b < NB; b++) bbuf[u][b] = ldv<BV>(bp[b] + (size_t)sn * 2 * J.ldx);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < PD; u++) fill(u, cur + 2 * u);
+        for (int ti = t_begin; ti < t_end; ti++) {
+            const int nxt2 = tile_row(ti + 2);      // (scalar load, consumed one tile later)
+#pragma unroll
+            for (int gi = 0; gi < 16 / PD; gi++) {
+#pragma unroll
+                for (int u = 0; u < PD; u++) {
+                    consume(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sn = gi * PD + u + PD;              // the step this slot holds next: same tile, or the next one
+                    fill(u, (sn < 16 ? cur : nxt) + 2 * (sn & 15));   // (past the last tile: harmless re-load, never consumed)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            cur = nxt; nxt = nxt2;
         }
     }
-    // remainder (< PD steps): their rows are exactly what slots 0 .. rem-1 were refilled (or preloaded) with
-    const int rem = nsteps - ngroups * PD;
-#pragma unroll
-    for (int u = 0; u < PD; u++)
-        if (u < rem) consume(u);
     // workgroup reduction in LDS, ldsW[m * ldl + c] with ldl = 32*CT: the four waves take turns (barrier between turns) and
     // use plain stores / read-add-writes -- ds_add_f32 runs at 0.33 lanes/clk/CU on MI355X (tools/lds_atomic_bench.hip:
     // 37x slower than ds_add_u32, ~200x slower than plain LDS traffic) and 4 x 16 k float atomics cost ~15 % of this kernel
@@ -1388,30 +1523,31 @@ __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
     const WgradJob J = a.job[j];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane & 31, h = lane >> 5;
     const int blk = (int)blockIdx.x - J.first_block;
-    int n_begin = blk * J.chunk, n_end = n_begin + J.chunk;
-    if (n_end > a.Npad) n_end = a.Npad;
-    // four waves split the chunk (multiples of 2 Gaussians)
-    const int len = n_end > n_begin ? n_end - n_begin : 0;
-    const int per = ((len / 4) + 1) & ~1;
-    int wb = n_begin + wave * per, we = wb + per;
-    if (wb > n_end) wb = n_end;
-    if (we > n_end) we = n_end;
+    // this workgroup's share of the live tiles, split over its four waves
+    const long long nlive = (long long)(int)as_const(a.counters)[1];
+    const const_u32p live_list = as_const(a.live);
+    const int t0 = (int)(nlive * blk / J.nblocks), t1 = (int)(nlive * (blk + 1) / J.nblocks);
+    if (t1 <= t0) return;           // (uniform: nothing to add to the weight gradients)
+    const int per = (t1 - t0 + 3) / 4;
+    int wb = t0 + __builtin_amdgcn_readfirstlane(wave) * per, we = wb + per;      // (wave-uniform: the list is read with scalar loads)
+    if (wb > t1) wb = t1;
+    if (we > t1) we = t1;
     float* ldsW = lds;
     float* ldsB = lds + W * W;
     const int CTn = (J.ncols + 31) / 32;
     // (every wave joins, also one whose slice is empty: the reduction inside is a workgroup-wide protocol)
-    if (J.ncols == W) wgrad_wave<WT, WT, true, WG_PD>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 1) wgrad_wave<WT, 1, false, 16>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 2) wgrad_wave<WT, 2, false, 12>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if (CTn == 3) wgrad_wave<WT, 3, false, 8>(J, W, wb, we, ldsW, ldsB, g, h, wave);
-    else if constexpr (WT != 4) wgrad_wave<WT, 4, false, WG_PD>(J, W, wb, we, ldsW, ldsB, g, h, wave);   // (W = 128, 128 columns) is the interleaved case
+    if (J.ncols == W) wgrad_wave<WT, WT, true, 8>(J, W, live_list, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 1) wgrad_wave<WT, 1, false, 16>(J, W, live_list, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 2) wgrad_wave<WT, 2, false, 16>(J, W, live_list, wb, we, ldsW, ldsB, g, h, wave);
+    else if (CTn == 3) wgrad_wave<WT, 3, false, 8>(J, W, live_list, wb, we, ldsW, ldsB, g, h, wave);
+    else if constexpr (WT != 4) wgrad_wave<WT, 4, false, 8>(J, W, live_list, wb, we, ldsW, ldsB, g, h, wave);   // (W = 128, 128 columns) is the interleaved case
     const int ldl = J.ncols == W ? W : 32 * CTn;
     for (int i = threadIdx.x; i < W * ldl; i += 256) {
         const int m = i / ldl, c = i - m * ldl;
         const float v = ldsW[i];
         if (c < J.ncols && v != 0.f) atomicAdd(&J.dW[(size_t)m * J.ldw + c], v);
     }
-    if ((int)threadIdx.x < W) atomicAdd(&J.db[threadIdx.x], ldsB[threadIdx.x]);
+    if ((int)threadIdx.x < W && ldsB[threadIdx.x] != 0.f) atomicAdd(&J.db[threadIdx.x], ldsB[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ D4 plane grads
@@ -1431,6 +1567,7 @@ struct PlaneGradArgs {
     int lds_off[FDGS_MAX_LEVELS][3];  // float offset of the LDS tile of time plane k = 2,4,5 (axis a = 0,1,2); -1: global atomics
     int lds_floats;
     int per_block;                    // Gaussians per workgroup
+    const uint32_t* tile_live;        // [Npad/32] 1 = the tile's DFEAT rows were written by D2 (a dead tile's rows are garbage and count as zero)
 };
 constexpr int PG_THREADS = 512;
 __host__ __device__ __forceinline__ int time_plane_slot(int k) { return k == 2 ? 0 : (k == 4 ? 1 : (k == 5 ? 2 : -1)); }
@@ -1459,8 +1596,8 @@ __global__ void __launch_bounds__(PG_THREADS) deform_plane_grad_kernel(PlaneGrad
     if (n_begin < n_end) fetch_xyz(n_begin, xn);
     for (int nb = n_begin; nb < n_end; nb += GPB) {
         const int n_raw = nb + wave * GPW + gsub;
-        const bool live = n_raw < n_end;
-        const int n = live ? n_raw : n_end - 1;
+        const bool live = n_raw < n_end && a.tile_live[(n_raw < n_end ? n_raw : n_end - 1) >> 5] != 0u;
+        const int n = n_raw < n_end ? n_raw : n_end - 1;
         float q[4];
 #pragma unroll
         for (int i = 0; i < 3; i++) q[i] = (xn[i] - p.aabb[i]) * a.sc.inv2[i] - 1.0f;
@@ -1602,7 +1739,8 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __
 struct PlaneGradMArgs {
     PlaneGradArgs g;
     unsigned long long* prof;
-    int nchunks;
+    const uint32_t* chunks;      // ascending indices of the chunks that contain a live tile (tile_compact_kernel)
+    const uint32_t* counters;    // [2] = entries of `chunks`
     int off_dv, off_q, off_desc, off_dq, off_org;   // float offsets into the dynamic LDS
 };
 
@@ -1657,18 +1795,20 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
     const unsigned long long prof_t0 = prof_t;
 #endif
-    const int c_begin = (int)((long long)blockIdx.x * ma.nchunks / gridDim.x);         // contiguous chunks: spatial locality
-    const int c_end = (int)((long long)(blockIdx.x + 1) * ma.nchunks / gridDim.x);
+    const int nchunks = (int)as_const(ma.counters)[2];
+    const int c_begin = (int)((long long)blockIdx.x * nchunks / gridDim.x);         // contiguous runs of the chunk list: spatial locality
+    const int c_end = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
     const float tq = p.time_scalar;
-    for (int chunk = c_begin; chunk < c_end; chunk++) {
+    for (int ci = c_begin; ci < c_end; ci++) {
+        const int chunk = (int)as_const(ma.chunks)[ci];
         const int n0 = chunk * G;
         // ---- S0: coordinates -> LDS, per-axis minimum over the chunk (the texel index is monotonic in the coordinate, so the
         // window origin of every level follows from the three minima)
         if (tid >= PGM_T - 40) s_cnt_all[tid - (PGM_T - 40)] = 0;
         if (tid < G) {
             const int n = n0 + tid;
-            const bool live = n < p.N;
-            const int nn = live ? n : p.N - 1;
+            const int nn = n < p.N ? n : p.N - 1;
+            const bool live = n < p.N && a.tile_live[nn >> 5] != 0u;   // (rows of dead tiles do not stretch the window)
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const float q = (p.xyz[3 * (size_t)nn + i] - p.aabb[i]) * a.sc.inv2[i] - 1.0f;
@@ -1701,11 +1841,11 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
             for (int b = 0; b < NB; b++) {
                 const int gl = b * (GPW * NW) + gl_s;
                 const int n = n0 + gl;
-                const bool live = n < p.N;
+                const bool live = n < p.N && a.tile_live[n >> 5] != 0u;     // (a dead tile's DFEAT rows were never written)
                 float q[4];
                 q[0] = s_q[gl]; q[1] = s_q[G + gl]; q[2] = s_q[2 * G + gl]; q[3] = tq;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 df = *reinterpret_cast<const float4*>(a.DFEAT + (size_t)(live ? n : p.N - 1) * a.F + lvl * C + 4 * cg);
+                float4 df = *reinterpret_cast<const float4*>(a.DFEAT + (size_t)(n < p.N ? n : p.N - 1) * a.F + lvl * C + 4 * cg);
                 if (!live) df = z4;
                 float4 vk[6], sk[6], tk[6];
                 float dsx[6], dsy[6];
@@ -2160,6 +2300,20 @@ static SavedLayout saved_layout(const fdgs_deform_params* p) {
     return s;
 }
 
+// scratch of fdgs_deform_bwd (float offsets): the packed gradient rows, DIRECTLY followed by the per-tile flags (the layout
+// include/fdgs.h promises to fdgs_raster_bwd's epilogue), the lists built from them, then the inter-kernel arrays
+struct BwdLayout { size_t G, flags, live, chunks, counters, DH1, DHID, RH, FEAT, DFEAT, floats; };
+static BwdLayout bwd_layout(const fdgs_deform_params* p) {
+    BwdLayout b;
+    const size_t Np = npad_of(p->N), F = (size_t)p->C * p->L, W = p->W, nt = Np / 32;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t r = o; o = (o + n + 63) / 64 * 64; return r; };
+    b.G = take(Np * GCOLS); b.flags = take(nt); b.live = take(nt + 4); b.chunks = take(nt); b.counters = take(64);
+    b.DH1 = take(Np * W * (size_t)active_heads(p)); b.DHID = take(Np * W); b.RH = take(Np * W); b.FEAT = take(Np * F); b.DFEAT = take(Np * F);
+    b.floats = o;
+    return b;
+}
+
 }  // namespace fdgs
 
 using namespace fdgs;
@@ -2230,8 +2384,20 @@ extern "C" int fdgs_deform_bwd_scratch_bytes(const fdgs_deform_params* p, size_t
     int rc = validate_deform(p);
     if (rc) return rc;
     FDGS_REQUIRE(bytes, "bytes is NULL");
-    const size_t Np = npad_of(p->N), F = (size_t)p->C * p->L, W = p->W;
-    *bytes = Np * (GCOLS + (size_t)active_heads(p) * W + 2 * W + 2 * F) * sizeof(float) + 1024;
+    *bytes = bwd_layout(p).floats * sizeof(float) + 1024;
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_deform_bwd_live_tiles(void* stream_, const fdgs_deform_params* p, const void* scratch, uint32_t* out_host) {
+    int rc = validate_deform(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(scratch && out_host, "NULL pointer");
+    const BwdLayout bl = bwd_layout(p);
+    uint32_t c[4] = {0, 0, 0, 0};
+    FDGS_HIP_CHECK(hipMemcpyAsync(c, reinterpret_cast<const float*>(scratch) + bl.counters, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    FDGS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_));
+    out_host[0] = c[1]; out_host[1] = c[3]; out_host[2] = c[2];
+    out_host[3] = (c[3] + 3) / 4;     // (reported in 128-Gaussian units)
     return FDGS_OK;
 }
 
@@ -2250,25 +2416,37 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     const int nh = active_heads(p);
     BwdScratch s;
     float* base = reinterpret_cast<float*>(g->scratch);
+    const BwdLayout bl = bwd_layout(p);
     s.Npad = (int)Np;
-    s.G = base; base += Np * GCOLS;
-    s.DH1 = base; base += Np * W * nh;
-    s.DHID = base; base += Np * W;
-    s.RH = base; base += Np * W;
-    s.FEAT = base; base += Np * F;
-    s.DFEAT = base;
+    s.G = base + bl.G; s.DH1 = base + bl.DH1; s.DHID = base + bl.DHID; s.RH = base + bl.RH; s.FEAT = base + bl.FEAT; s.DFEAT = base + bl.DFEAT;
+    s.tile_live = reinterpret_cast<uint32_t*>(base + bl.flags); s.live = reinterpret_cast<uint32_t*>(base + bl.live);
+    s.chunks = reinterpret_cast<uint32_t*>(base + bl.chunks); s.counters = reinterpret_cast<uint32_t*>(base + bl.counters);
     // prep: activation Jacobians, identity paths, packed gradient rows
     PrepArgs pa{};
     pa.N = p->N; pa.Npad = (int)Np; pa.activate = p->activate; pa.dc_stride = p->shs_dc_stride; pa.rest_stride = p->shs_rest_stride;
     pa.g_xyz = g->g_xyz; pa.g_scales = g->g_scales; pa.g_rot = g->g_rotations; pa.g_opacity = g->g_opacity; pa.g_shs = g->g_shs;
     pa.out_scales = g->out_scales; pa.out_rot = g->out_rotations; pa.out_opacity = g->out_opacity; pa.rot_norm = g->rot_norm;
     pa.d_xyz = g->d_xyz; pa.d_scales = g->d_scales; pa.d_rot = g->d_rotations; pa.d_opacity = g->d_opacity;
-    pa.d_shs_dc = g->d_shs_dc; pa.d_shs_rest = g->d_shs_rest; pa.G = s.G;
+    pa.d_shs_dc = g->d_shs_dc; pa.d_shs_rest = g->d_shs_rest; pa.G = s.G; pa.tile_live = s.tile_live;
     if (!g->packed_rows_ready) {    // (1: fdgs_raster_bwd's deformation epilogue already wrote G and the identity paths)
         { FDGS_TIMED("deform_bwd_prep", stream); hipLaunchKernelGGL(deform_bwd_prep_kernel, dim3(cdiv((long long)Np, 256)), dim3(256), 0, stream, pa); }
         FDGS_LAUNCH_CHECK("deform_bwd_prep", 0, stream);
     }
     if (nh == 0) return FDGS_OK;  // no head active: the deformation is the identity
+    // plane-gradient kernel choice and its chunk size (the chunk list is built for it)
+    const int d4_env = tunable("FDGS_D4_MFMA", -1);
+    const bool use_mfma = !p->time && (d4_env >= 0 ? d4_env != 0 : g->spatially_ordered != 0);
+    const int nwv = tunable("FDGS_D4_WAVES", 8) == 4 ? 4 : 8;
+    const int Gc = (nwv == 8 ? 2048 : 1024) / p->C;
+    {
+        // tiles with a non-zero gradient row -> lists (packed_rows_ready = 1: rows without flags: every tile counts as live)
+        CompactArgs ca{};
+        ca.flags = s.tile_live; ca.live = s.live; ca.chunks = s.chunks; ca.counters = s.counters;
+        ca.ntiles = (int)(Np / 32); ca.tpc = Gc / 32;
+        ca.skip = (tunable("FDGS_SKIP_DEAD", 1) != 0 && g->packed_rows_ready != 1) ? 1 : 0;
+        { FDGS_TIMED("tile_compact", stream); hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, stream, ca); }
+        FDGS_LAUNCH_CHECK("tile_compact", 0, stream);
+    }
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++)
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
@@ -2325,7 +2503,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     FDGS_LAUNCH_CHECK("deform_bwd_data", 0, stream);
     // weight gradients: one job per active head (dW1, db1) + the trunk (dW0, db0)
     WgradArgs wa{};
-    wa.Npad = (int)Np; wa.W = (int)W;
+    wa.Npad = (int)Np; wa.W = (int)W; wa.live = s.live; wa.counters = s.counters;
     int nj = 0;
     for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) {
         if (!p->head_on[hd]) continue;
@@ -2359,14 +2537,12 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         for (int j = 0; j < nj; j++) { nbs[j] = (int)((long long)total_wgs * work[j] / total_work); if (nbs[j] < 1) nbs[j] = 1; used += nbs[j]; }
         for (int j = 0; used < total_wgs; j = (j + 1) % nj) { nbs[j]++; used++; }   // leftovers round-robin, heads first
         int first = 0;
+        const int ntl = (int)(Np / 32);
         for (int j = 0; j < nj; j++) {
             WgradJob& J = wa.job[j];
             int nb = nbs[j];
-            int chunk = (int)((Np + nb - 1) / nb);
-            chunk = (chunk + 7) / 8 * 8;        // four waves x two Gaussians per MFMA k-step
-            if (chunk < 64) chunk = 64;
-            nb = (int)((Np + chunk - 1) / chunk);
-            J.first_block = first; J.nblocks = nb; J.chunk = chunk;
+            if (nb > ntl) nb = ntl;             // (never more workgroups than tiles)
+            J.first_block = first; J.nblocks = nb;
             first += nb;
         }
         if (W == 128) { FDGS_TIMED("deform_wgrad", stream); hipLaunchKernelGGL((deform_wgrad_kernel<4>), dim3(first), dim3(256), 0, stream, wa); }
@@ -2376,21 +2552,17 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     // plane + coordinate gradients
     bool any_plane = g->d_xyz != nullptr;
     PlaneGradArgs ga{};
-    ga.p = *p; ga.sc = aabb_scale(p); ga.DFEAT = s.DFEAT; ga.d_xyz = g->d_xyz; ga.F = (int)F;
+    ga.p = *p; ga.sc = aabb_scale(p); ga.DFEAT = s.DFEAT; ga.d_xyz = g->d_xyz; ga.F = (int)F; ga.tile_live = s.tile_live;
     for (int l = 0; l < p->L; l++)
         for (int k = 0; k < 6; k++) { ga.d_planes[l][k] = g->d_planes[l][k]; any_plane = any_plane || g->d_planes[l][k]; }
     if (any_plane) {
         // matrix-core splat (default whenever one frame time is shared by all Gaussians, i.e. on the render() path): the
         // fixed LDS part is the dv tile, coordinates, descriptors; the time rows get what is left of the 160 KB
         // FDGS_D4_MFMA = 1 / 0 forces a kernel (A/B, tests); otherwise the caller's order hint decides
-        const int d4_env = tunable("FDGS_D4_MFMA", -1);
-        const bool use_mfma = !p->time && (d4_env >= 0 ? d4_env != 0 : g->spatially_ordered != 0);
         // workgroup shape of the splat: 8 waves, one workgroup per CU (default); FDGS_D4_WAVES=4 selects 4-wave workgroups with half
         // the chunk, two per CU where the LDS allows -- measured equal on BASELINE config 4 (0.331 vs 0.322 ms: overlapping one
         // workgroup's sampling with the other's matrix-core phase buys what the smaller chunks lose in merging), kept for A/B
         auto fixed_floats_of = [&](int nwv) { const int Gv = (nwv == 8 ? 2048 : 1024) / p->C; return 6 * Gv * p->C + 3 * Gv + 13 * Gv + 3 * Gv + (96 + 9 * Gv) + 64; };
-        const int nwv = tunable("FDGS_D4_WAVES", 8) == 4 ? 4 : 8;
-        const int Gc = (nwv == 8 ? 2048 : 1024) / p->C;
         const int fixed_floats = fixed_floats_of(nwv);
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
         // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
@@ -2425,7 +2597,8 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             (void)hipMemsetAsync(prof_dev, 0, prof_n * sizeof(unsigned long long), stream);
             ma.prof = prof_dev;
 #endif
-            ma.nchunks = cdiv(p->N, Gc);
+            ma.chunks = s.chunks; ma.counters = s.counters;
+            const int nchunks_max = cdiv(p->N, Gc);
             int o = (used + 63) / 64 * 64;
             ma.off_dv = o; o += 6 * Gc * p->C;
             ma.off_q = o; o += 3 * Gc;
@@ -2434,13 +2607,13 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             ma.off_org = o; o += 96 + 9 * Gc;
             const size_t lds_bytes = (size_t)o * 4;
             int blocks = tunable("FDGS_PGM_WGS", nwv == 4 ? 512 : 256);
-            if (blocks > ma.nchunks) blocks = ma.nchunks;
+            if (blocks > nchunks_max) blocks = nchunks_max;
             const void* fn = p->C == 16 ? (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 4>)
                                                      : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 8>))
                                         : (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 4>)
                                                      : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 8>));
-            static bool raised[4] = {false, false, false, false};
-            bool& r_ = raised[(p->C == 16 ? 0 : 2) + (nwv == 4 ? 0 : 1)];
+            static bool raised[FDGS_MAX_DEVICES][4] = {};      // (a function attribute is set per device)
+            bool& r_ = raised[current_device_slot()][(p->C == 16 ? 0 : 2) + (nwv == 4 ? 0 : 1)];
             if (!r_) {
                 FDGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 r_ = true;
@@ -2483,8 +2656,8 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         const int blocks = cdiv(p->N, per_block);
         const size_t lds_bytes = (size_t)used * 4;
         if (lds_bytes > 64 * 1024) {   // above the default dynamic-LDS limit: opt in once per kernel
-            static bool raised16 = false, raised32 = false;
-            bool& raised = p->C == 16 ? raised16 : raised32;
+            static bool raised_pc[FDGS_MAX_DEVICES][2] = {};
+            bool& raised = raised_pc[current_device_slot()][p->C == 16 ? 0 : 1];
             if (!raised) {
                 const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_kernel<16>)
                                             : reinterpret_cast<const void*>(&deform_plane_grad_kernel<32>);

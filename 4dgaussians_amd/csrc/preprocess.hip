@@ -275,6 +275,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
                 row[10] = dop;
             }
         }
+        if (e.tile_flags) {
+            // per 32-row tile of the deformation backward: does any row carry a gradient at all?  (culled / occluded / off-screen
+            // Gaussians do not: fdgs_deform_bwd skips tiles made of them -- a zero row adds exactly zero to every sum)
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < 11; k++) nz = nz || (row[k] != 0.f);
+#pragma unroll
+            for (int k = 0; k < 48; k++) nz = nz || (dsh[k] != 0.f);
+            const unsigned long long m = __ballot(nz);
+            if (lane == 0) {
+                uint32_t* tl = reinterpret_cast<uint32_t*>(e.G + (size_t)e.Npad * 64) + (n0 >> 5);
+                tl[0] = (uint32_t)(m & 0xffffffffull) != 0u ? 1u : 0u;
+                tl[1] = (uint32_t)(m >> 32) != 0u ? 1u : 0u;
+            }
+        }
         float* small = buf;              // [64][16]
         float* sh = buf + 64 * 16;       // [64][48]
         __builtin_amdgcn_wave_barrier();

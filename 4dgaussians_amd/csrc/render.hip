@@ -122,18 +122,22 @@ struct RenderBwdArgs {
                   // 6,7,8 rgb | 9 depth | 10..15 unused.  One 64-B line per Gaussian => one atomic line-op per (tile,Gaussian)
 };
 
-constexpr int ACC_STRIDE = 257;  // 10 rows of 256 sums, odd row stride => conflict-free LDS atomics and flush
-
 // DEPTH: a gradient w.r.t. the depth image was handed in (dL_ddepth != NULL).  The reference's training loss never uses it
 // (utils/scene_utils.py:29 reads depth under no_grad), so the common instantiation drops the depth accumulators, their
-// row reduction and the tenth LDS column.
-template <bool DEPTH>
+// row reduction and the tenth value of the per-Gaussian sums.
+// ROUND = list entries staged per round (256 or 128).  The four waves of the tile meet in per-WAVE LDS slots
+// sAcc[entry][wave][NV]: a wave that hits an entry finishes the sum over its 64 pixels in registers (DPP inside the 16-lane rows, then
+// permlane16/32 swaps across the rows on the ONE value each lane carries) and lanes 0..NV-1 store it with a plain ds_write; the flush
+// adds the four slots.  (Until round 3 the rows met in LDS float atomics on one shared slot -- ds_add_f32 sustains 0.33 lanes/clk/CU,
+// profiles/r01_lds_atomic_microbench.txt, and rocprofv3 showed the waves waiting 39 % of their cycles.)
+template <bool DEPTH, int ROUND>
 __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
-    __shared__ float4 sA[256], sB[256], sC[256];
-    __shared__ uint32_t sGid[256];
-    __shared__ float sAcc[10 * ACC_STRIDE];
+    constexpr int NV = DEPTH ? 10 : 9;
+    __shared__ float4 sA[ROUND], sB[ROUND], sC[ROUND];
+    __shared__ uint32_t sGid[ROUND];
+    __shared__ float sAcc[ROUND * 4 * NV];
     __shared__ uint32_t sMax[4];
     const int t = threadIdx.x, lane = t & 63;
     const int x = (tile % a.gx) * TILE + (t & 15), y = (tile / a.gx) * TILE + (t >> 4);
@@ -143,12 +147,15 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     const uint2 range = a.ranges[tile];
     const float T_final = inside ? a.final_T[pix] : 0.f;
     const uint32_t last_contributor = inside ? a.n_contrib[pix] : 0u;
-    // the tile only ever needs the first max(n_contrib) entries of its list
+    // the tile only ever needs the first max(n_contrib) entries of its list -- and each WAVE (a 16x4 pixel strip) only the first
+    // max over its own 64 pixels: walking back to front, the entries behind that are skipped without being evaluated
+    int wave_todo;
     {
         uint32_t m = last_contributor;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
         if (lane == 0) sMax[t >> 6] = m;
+        wave_todo = (int)m;
     }
     __syncthreads();
     uint32_t mx = sMax[0]; mx = sMax[1] > mx ? sMax[1] : mx; mx = sMax[2] > mx ? sMax[2] : mx; mx = sMax[3] > mx ? sMax[3] : mx;
@@ -161,20 +168,22 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
     float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f, last_alpha = 0.f;
-    const int rounds = (toDo + 255) / 256;
+    const int rounds = (toDo + ROUND - 1) / ROUND;
+    const int wv_ = t >> 6;
     for (int r = 0; r < rounds; r++) {
-        const int e = toDo - 1 - (r * 256 + t);  // list entry (0-based from the front) staged by this thread
-        if (e >= 0) {
+        const int e = toDo - 1 - (r * ROUND + t);  // list entry (0-based from the front) staged by this thread
+        if (t < ROUND && e >= 0) {
             const uint32_t gid = a.pair_gid[range.x + e];
             sGid[t] = gid; sA[t] = a.recA[gid]; sB[t] = a.recB[gid]; sC[t] = a.recC[gid];
         }
-#pragma unroll
-        for (int k = 0; k < 10; k++) sAcc[k * ACC_STRIDE + t] = 0.f;
+        for (int k = t; k < ROUND * 4 * NV; k += 256) sAcc[k] = 0.f;      // (an entry a wave does not hit keeps a zero slot)
         __syncthreads();
-        const int rem = toDo - r * 256;
-        const int lim = rem < 256 ? rem : 256;
-        for (int j = 0; j < lim; j++) {
-            const uint32_t ej = (uint32_t)(toDo - 1 - (r * 256 + j));
+        const int rem = toDo - r * ROUND;
+        const int lim = rem < ROUND ? rem : ROUND;
+        int j0 = toDo - wave_todo - r * ROUND;        // first staged entry of this round that one of the wave's pixels blended
+        j0 = j0 < 0 ? 0 : j0;
+        for (int j = j0; j < lim; j++) {
+            const uint32_t ej = (uint32_t)(toDo - 1 - (r * ROUND + j));
             const float4 A = sA[j];
             const float4 B = sB[j];
             const float dx = A.x - pxf, dy = A.y - pyf;
@@ -215,9 +224,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
                 g_cxx = -0.5f * gdx * dx * dL_dG; g_cxy = -0.5f * gdx * dy * dL_dG; g_cyy = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            // per-Gaussian sums over the wave's 64 pixels: DPP butterflies inside each 16-lane row (4 instructions per
-            // value), then lanes 0..9 of EVERY row add "their" value into the LDS slot -- the four rows meet in the LDS
-            // atomic unit instead of in two more permlane swap stages per value (120 -> 50 VALU instructions per hit)
+            // per-Gaussian sums over the wave's 64 pixels: DPP butterflies inside each 16-lane row (4 instructions per value); lane
+            // `sub` of every row then picks value `sub` and the four rows are added with two permlane swaps on that ONE value
             g_mx = row_allsum(g_mx); g_my = row_allsum(g_my);
             g_cxx = row_allsum(g_cxx); g_cxy = row_allsum(g_cxy); g_cyy = row_allsum(g_cyy);
             g_op = row_allsum(g_op);
@@ -228,18 +236,30 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
             v = sub == 1 ? g_my : v; v = sub == 2 ? g_cxx : v; v = sub == 3 ? g_cxy : v; v = sub == 4 ? g_cyy : v;
             v = sub == 5 ? g_op : v; v = sub == 6 ? g_c0 : v; v = sub == 7 ? g_c1 : v; v = sub == 8 ? g_c2 : v;
             if (DEPTH) v = sub == 9 ? g_d : v;
-            if (sub < (DEPTH ? 10 : 9)) atomicAdd(&sAcc[sub * ACC_STRIDE + j], v);
+            {
+                auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            {
+                auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            if (lane < NV) sAcc[(j * 4 + wv_) * NV + lane] = v;      // this wave's slot of entry j: plain store, no other writer
         }
         __syncthreads();
         // flush: 16 lanes own the 16-float gradient line of one staged Gaussian, so every atomic instruction covers four
         // whole 64-byte lines (measured: scattered float atomics cost ~1 line-op each at ~20 G line-ops/s on MI355X)
         {
-            const int wv = t >> 6, sub = lane & 15;
+            const int sub = lane & 15;
 #pragma unroll 4
-            for (int i = 0; i < 16; i++) {
-                const int jj = wv * 64 + i * 4 + (lane >> 4);
+            for (int i = 0; i < ROUND / 16; i++) {
+                const int jj = wv_ * (ROUND / 4) + i * 4 + (lane >> 4);
                 if (jj < lim) {
-                    const float v = sub < 10 ? sAcc[sub * ACC_STRIDE + jj] : 0.f;
+                    float v = 0.f;
+                    if (sub < NV) {
+                        const float* sl = &sAcc[jj * 4 * NV + sub];
+                        v = (sl[0] + sl[NV]) + (sl[2 * NV] + sl[3 * NV]);
+                    }
                     if (v != 0.f) atomicAdd(&a.gacc[(size_t)sGid[jj] * 16 + sub], v);
                 }
             }
@@ -313,8 +333,16 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         const int ntiles = il.gx * il.gy;
         {
             FDGS_TIMED("render_bwd", stream);
-            if (g->dL_ddepth) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+            // entries staged per round: 128 keeps six workgroups per CU (25 KB of LDS each), 256 halves the barriers at three per CU
+            const int round = tunable("FDGS_RBWD_ROUND", 128);
+            const dim3 grid(8 * ((ntiles + 7) / 8));
+            if (g->dL_ddepth) {
+                if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<true, 256>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((render_bwd_kernel<true, 128>), grid, dim3(256), 0, stream, a);
+            } else {
+                if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<false, 256>), grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((render_bwd_kernel<false, 128>), grid, dim3(256), 0, stream, a);
+            }
         }
         FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);
     }

@@ -231,35 +231,78 @@ def _fill_params(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
     return p
 
 
-_aabb_cache = [None, None, None]   # (weakref to the tensor object, its version counter, host floats)
+# Host-side caches keyed by tensor OBJECT (weak references: an entry dies with its tensor; keying on data_ptr() is wrong -- the caching
+# allocator hands a freed tensor's address to the next model's).  Small dicts, not single entries: code that alternates between
+# models (merge_many_4dgs.py:85-135 renders three per frame) must not pay a host sync per call.
+_CACHE_MAX = 16
+_aabb_cache = {}     # id(aabb) -> (weakref, (version, data_ptr), host floats)
+_order_cache = {}    # id(xyz)  -> (weakref, (shape, data_ptr), ordered?)
+_fresh_streak = {}   # shape -> (measurements made on non-Parameter tensors of this shape, last answer)
+
+
+def _cache_get(cache, t, key):
+    e = cache.get(id(t))
+    if e is not None and e[0]() is t and e[1] == key:
+        return e
+    return None
+
+
+def _cache_put(cache, t, key, val):
+    import weakref
+    if len(cache) >= _CACHE_MAX:
+        for k in [k for k, e in cache.items() if e[0]() is None]:
+            del cache[k]
+        while len(cache) >= _CACHE_MAX:
+            del cache[next(iter(cache))]
+    cache[id(t)] = (weakref.ref(t), key, val)
+
+
+def invalidate_caches(*tensors):
+    """Forget what is cached about these tensors (all tensors when called without arguments).  fdgs.densify calls it for every position
+    tensor it replaces or permutes IN PLACE (a model without an optimizer keeps its Parameter object through spatial_reorder);
+    code that writes `xyz.data = ...` itself must do the same -- a stale order hint only ever selects the slower of two equivalent
+    plane-gradient kernels, a stale aabb would be wrong, which is why that one is also keyed on the tensor's version counter."""
+    if not tensors:
+        _aabb_cache.clear()
+        _order_cache.clear()
+        _fresh_streak.clear()
+        return
+    for t in tensors:
+        _aabb_cache.pop(id(t), None)
+        _order_cache.pop(id(t), None)
 
 
 def _aabb_to_host(aabb):
-    """The 6 aabb floats are needed in the kernel-argument struct; cache the host copy per tensor OBJECT and version.
-    (Keying on data_ptr() is wrong: the caching allocator hands a freed aabb's address to the next model's aabb.)"""
-    import weakref
-    ref, ver, vals = _aabb_cache
+    """The 6 aabb floats are needed in the kernel-argument struct; the host copy is cached per tensor object, version and address."""
     key = (aabb._version, aabb.data_ptr())
-    if ref is not None and ref() is aabb and ver == key:
-        return vals
+    e = _cache_get(_aabb_cache, aabb, key)
+    if e is not None:
+        return e[2]
     vals = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
-    _aabb_cache[0], _aabb_cache[1], _aabb_cache[2] = weakref.ref(aabb), key, vals
+    _cache_put(_aabb_cache, aabb, key, vals)
     return vals
-
-
-_order_cache = [None, None, False]   # (weakref to the position tensor object, its shape, ordered?)
 
 
 def spatial_order_hint(xyz):
     """True when consecutive rows of `xyz` are spatial neighbours (the set was ordered along a space-filling curve, e.g. by
     fdgs.densify.spatial_reorder).  Measured, not declared: mean distance between consecutive positions against the bounding-box
-    diagonal (random order: ~0.38; Hilbert order at 10^4..10^6 points: < 0.05), once per tensor OBJECT -- the train loop only creates
-    a new position Parameter when the set is rebuilt (densify / prune / reorder), optimizer steps move it in place and do not change
-    the order.  Decides only which of two equivalent plane-gradient kernels runs (fdgs_deform_grads::spatially_ordered)."""
-    import weakref
-    ref, shape, val = _order_cache
-    if ref is not None and ref() is xyz and shape == tuple(xyz.shape):
-        return val
+    diagonal (random order: ~0.38; Hilbert order at 10^4..10^6 points: < 0.05), once per tensor OBJECT and storage -- the train loop only
+    creates a new position Parameter when the set is rebuilt (densify / prune / reorder), optimizer steps move it in place and do not
+    change the order.  Decides only which of two equivalent plane-gradient kernels runs (fdgs_deform_grads::spatially_ordered).
+    A tensor that is not a leaf Parameter (a clone / view made per call) is not measured at all: three reductions and a blocking
+    `.item()` per frame would cost more than the slower kernel; pass `ordered=` to deform() to declare its order."""
+    key = (tuple(xyz.shape), xyz.data_ptr())
+    e = _cache_get(_order_cache, xyz, key)
+    if e is not None:
+        return e[2]
+    if not isinstance(xyz, torch.nn.Parameter):
+        # a caller that hands in a FRESH tensor on every call (clone, detached copy) would pay the measurement per frame: after a few
+        # consecutive misses on non-Parameter tensors of one shape the last answer for that shape is reused instead
+        streak = _fresh_streak.get(key[0], (0, False))
+        if not xyz.is_leaf:
+            return streak[1]
+        if streak[0] >= 4:
+            return streak[1]
     val = False
     if xyz.shape[0] >= 256:
         with torch.no_grad():
@@ -267,7 +310,11 @@ def spatial_order_hint(xyz):
             step = (x[1:] - x[:-1]).norm(dim=1).mean()
             diag = (x.max(0).values - x.min(0).values).norm().clamp_min(1e-20)
             val = bool((step / diag).item() < 0.1)
-    _order_cache[0], _order_cache[1], _order_cache[2] = weakref.ref(xyz), tuple(xyz.shape), val
+    _cache_put(_order_cache, xyz, key, val)
+    if not isinstance(xyz, torch.nn.Parameter):
+        _fresh_streak[key[0]] = (_fresh_streak.get(key[0], (0, False))[0] + 1, val)
+        if len(_fresh_streak) > 64:
+            _fresh_streak.clear()
     return val
 
 
@@ -377,9 +424,25 @@ def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False):
     return b
 
 
+# Diagnostics (bench.py's FLOP accounting, tests): when set, every deformation backward reads back how many 32-row tiles it actually
+# processed -- (live tiles, tiles, live plane-gradient chunks, chunks) -> `last_live_tiles`.  One blocking read-back per backward: off
+# by default.
+COUNT_LIVE_TILES = False
+last_live_tiles = None
+
+
+def note_live_tiles(st, b):
+    global last_live_tiles
+    if COUNT_LIVE_TILES:
+        out = (_lib.c_uint32 * 4)()
+        check(_lib.lib().fdgs_deform_bwd_live_tiles(stream_ptr(), st.p, b.g.scratch, out))
+        last_live_tiles = tuple(int(x) for x in out)
+
+
 def backward_run(st, b):
     """Launches fdgs_deform_bwd on prepared buffers and returns the gradients in _DeformFunction's input order (after cfg, t_scalar)."""
     check(_lib.lib().fdgs_deform_bwd(stream_ptr(), st.p, b.g))
+    note_live_tiles(st, b)
     cfg, sh = st.cfg, st.shapes
     d_mlp = b.d_mlp
     for h in range(NUM_HEADS):  # parameters of a disabled head receive no gradient (as under autograd)

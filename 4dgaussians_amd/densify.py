@@ -17,6 +17,7 @@ contract: new nn.Parameter objects in the same param_groups, `exp_avg` / `exp_av
 zeros for new rows, `step` untouched.  No CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -28,6 +29,11 @@ GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
         "rotation": "_rotation"}
 PLAN_DENSIFY, PLAN_PRUNE, PLAN_MASK = 0, 1, 2
+# densify / prune / prune_points leave the set in the reference's row order (kept originals, clones, first children, second children)
+# and then -- unless switched off -- put it back along the Hilbert curve (spatial_reorder): the order is semantically free, and the
+# deformation kernels are measured (bench.py) in the order the train loop keeps.  FDGS_AUTO_REORDER=0 / `reorder=False` keeps the
+# reference's row order (what the row-order tests compare).  Cost: bench.py's "reorder" figure, once per densification interval.
+AUTO_REORDER = os.environ.get("FDGS_AUTO_REORDER", "1") != "0"
 
 
 def _rows(n, tail, dev, dtype=torch.float32):
@@ -102,6 +108,15 @@ def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.
         # sampled -- rank 0's samples are used everywhere instead of relying on lock-stepped per-rank RNG streams
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the broadcast needs the same shape on every rank: check the plan first (a forgotten allreduce_densification_stats or a
+            # threshold comparison that fell the other way on one rank would otherwise hang or corrupt memory inside the collective)
+            mine = torch.tensor([kept, clones, splits], device=dev, dtype=torch.int64)
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError(f"densify: ranks disagree on the plan (kept, clones, splits): min {lo.tolist()} max {hi.tolist()}, this rank "
+                                   f"{mine.tolist()} -- reduce the densification statistics over the ranks first (parallel.allreduce_densification_stats)")
             dist.broadcast(normals, src=0)
     if normals is not None:
         normals = _f32(normals)
@@ -165,23 +180,36 @@ def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.
 
 
 def densify(pc, max_grad, min_opacity, extent, max_screen_size, density_threshold=None, displacement_scale=None, model_path=None,
-            iteration=None, stage=None, normals=None):
+            iteration=None, stage=None, normals=None, reorder=None):
     """GaussianModel.densify (scene/gaussian_model.py:495-500): clone the small high-gradient Gaussians, split the large
     ones into two.  `normals` ([2*splits, 3] standard-normal samples) may be supplied for reproducibility; by default they
-    come from torch.randn on the device.  Returns (kept, clones, splits)."""
-    return _restructure(pc, PLAN_DENSIFY, grad_threshold=float(max_grad), dense_size=float(pc.percent_dense) * float(extent),
-                        normals=normals, carry_stats=False)
+    come from torch.randn on the device.  `reorder` (default: AUTO_REORDER) re-orders the grown set along the Hilbert curve afterwards.
+    Returns (kept, clones, splits)."""
+    out = _restructure(pc, PLAN_DENSIFY, grad_threshold=float(max_grad), dense_size=float(pc.percent_dense) * float(extent),
+                       normals=normals, carry_stats=False)
+    _maybe_reorder(pc, reorder, changed=out[1] + out[2] > 0)
+    return out
 
 
-def prune(pc, max_grad, min_opacity, extent, max_screen_size):
+def _maybe_reorder(pc, reorder, changed):
+    """Back onto the space-filling curve after the set was rebuilt (new rows were appended at the tail / rows were dropped)."""
+    if ((AUTO_REORDER and changed) if reorder is None else reorder) and pc._xyz.shape[0] > 1:
+        spatial_reorder(pc)
+
+
+def prune(pc, max_grad, min_opacity, extent, max_screen_size, reorder=None):
     """GaussianModel.prune (scene/gaussian_model.py:481-494): drop transparent, screen-filling or oversized Gaussians."""
-    return _restructure(pc, PLAN_PRUNE, min_opacity=float(min_opacity), max_screen_size=float(max_screen_size or 0.0),
-                        max_world_size=0.1 * float(extent))
+    out = _restructure(pc, PLAN_PRUNE, min_opacity=float(min_opacity), max_screen_size=float(max_screen_size or 0.0),
+                       max_world_size=0.1 * float(extent))
+    _maybe_reorder(pc, reorder, changed=False)     # (dropping rows of an ordered set leaves it ordered: only an explicit reorder=True acts)
+    return out
 
 
-def prune_points(pc, mask):
+def prune_points(pc, mask, reorder=None):
     """GaussianModel.prune_points (scene/gaussian_model.py:350-365): drop the Gaussians where `mask` is True."""
-    return _restructure(pc, PLAN_MASK, drop_mask=mask)
+    out = _restructure(pc, PLAN_MASK, drop_mask=mask)
+    _maybe_reorder(pc, reorder, changed=False)
+    return out
 
 
 def reset_opacity(pc):
@@ -286,6 +314,7 @@ def spatial_reorder(pc, perm=None, curve="hilbert"):
     perm = perm.to(xyz.device)
     opt = getattr(pc, "optimizer", None)
     groups = _groups(pc) if opt is not None else None
+    from . import deformation as _deformation
     for n in GROUPS:
         old = getattr(pc, ATTR[n])
         data = old.detach().index_select(0, perm).contiguous()
@@ -293,6 +322,7 @@ def spatial_reorder(pc, perm=None, curve="hilbert"):
             with torch.no_grad():
                 old.data = data
             old.grad = None
+            _deformation.invalidate_caches(old)     # same Parameter object, new order: the cached order hint is stale
             continue
         new = nn.Parameter(data.requires_grad_(True))
         st = opt.state.get(old, None)

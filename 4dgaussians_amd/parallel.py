@@ -13,8 +13,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, world, device)."""
+def init_from_env(backend=None, timeout_s=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, world, device).
+    `timeout_s` (default FDGS_PG_TIMEOUT_S or 600) bounds every collective: a rank that died leaves its peers with an error after
+    minutes, not after the process-group default of tens of minutes."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -27,9 +29,12 @@ def init_from_env(backend=None):
                                "the frame-parallel path runs one process per GPU and never shares a device")
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        t = float(timeout_s if timeout_s is not None else os.environ.get("FDGS_PG_TIMEOUT_S", "600"))
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=t))
     return rank, world, device
 
 
@@ -53,23 +58,46 @@ def _spawn_entry(rank, world, port, fn, args):
             dist.destroy_process_group()
 
 
-def spawn_local(world, fn, args=()):
+def spawn_local(world, fn, args=(), poll_s=0.2, attempts=3):
     """Launcher-free form of `torch.distributed.run --nnodes=1 --nproc-per-node world`: starts `world` processes on this
     node, rank r with RANK = LOCAL_RANK = r (-> cuda:r in init_from_env), rendezvous on 127.0.0.1 at a free port, and
-    calls fn(*args) in each.  Raises if any rank exits non-zero.  `fn` must be importable (module-level)."""
+    calls fn(*args) in each.  All ranks are polled together: the first non-zero exit terminates the siblings (they would otherwise
+    sit in a collective until the process-group timeout) and raises.  The rendezvous port is probed and released before the children
+    bind it; if another process takes it in between, rank 0 dies with "address already in use" within a second and the launch is
+    retried on a new port (`attempts` times).  `fn` must be importable (module-level)."""
+    import time
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    port = _free_port()
-    procs = [ctx.Process(target=_spawn_entry, args=(r, world, port, fn, args)) for r in range(world)]
-    for p in procs:
-        p.start()
-    bad = []
-    for r, p in enumerate(procs):
-        p.join()
-        if p.exitcode != 0:
-            bad.append((r, p.exitcode))
-    if bad:
-        raise RuntimeError(f"spawn_local: ranks exited non-zero: {bad}")
+    last = None
+    for attempt in range(attempts):
+        port = _free_port()
+        procs = [ctx.Process(target=_spawn_entry, args=(r, world, port, fn, args)) for r in range(world)]
+        t0 = time.monotonic()
+        for p in procs:
+            p.start()
+        bad = []
+        while True:
+            codes = [p.exitcode for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad or all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+        if not bad:
+            return
+        for p in procs:                       # first failure: do not leave the others blocked in a collective
+            if p.exitcode is None:
+                p.terminate()
+        for p in procs:
+            p.join(10)
+            if p.exitcode is None:
+                p.kill()
+                p.join(5)
+        last = bad
+        # a rank-0 death in the first moments is what a lost rendezvous port looks like: retry on a fresh port; anything later is the
+        # job's own failure
+        if not (time.monotonic() - t0 < 5.0 and any(r == 0 for r, _ in bad)) or attempt == attempts - 1:
+            break
+    raise RuntimeError(f"spawn_local: ranks exited non-zero: {last}")
 
 
 def ranks_seen(device):

@@ -61,10 +61,11 @@ class _FusedRenderFunction(torch.autograd.Function):
         epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
         epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
         epi.assign = 1 if EPILOGUE_ASSIGN else 0
+        epi.tile_flags = 1        # per-tile non-zero flags behind the packed rows: the deformation backward skips all-zero tiles
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                      rstate.num_rendered, g))
-        b.g.packed_rows_ready = 1
+        b.g.packed_rows_ready = 2
         grads = _deformation.backward_run(st, b)       # (d_xyz, d_sc, d_rot, d_op, d_sha, d_shb, None [time], None [aabb], planes..., mlp...)
         return (None, None, None, g_means2D) + grads[:6] + grads[7:]
 
@@ -130,14 +131,16 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
             epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
             epi.assign = 1 if (EPILOGUE_ASSIGN and v == 0) else 0        # later views accumulate into what the first one assigned
+            epi.tile_flags = 1
             g.deform_epilogue = _lib.ctypes.pointer(epi)
             _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                          rstate.num_rendered, g))
             # this view's deformation backward: same output pointers and scratch (stream-ordered reuse), its own saved activations
             b.g.out_scales, b.g.out_rotations, b.g.out_opacity = _lib.ptr(saved[3 * v]), _lib.ptr(saved[3 * v + 1]), _lib.ptr(saved[3 * v + 2])
             b.g.rot_norm, b.g.saved = _lib.ptr(st.o_norm), _lib.ptr(st.saved_act)
-            b.g.packed_rows_ready = 1
+            b.g.packed_rows_ready = 2
             _lib.check(L.fdgs_deform_bwd(_lib.stream_ptr(), st.p, b.g))
+            _deformation.note_live_tiles(st, b)
             g_means2D.append(gm)
             keep.append((gc, gd, acc, epi))
         cfg, sh = st0.cfg, st0.shapes

@@ -113,6 +113,11 @@ typedef struct fdgs_raster_deform_epilogue {
     int assign;                  /* 0: the identity paths are accumulated (+=, caller zero-fills); 1: they are ASSIGNED (=): the caller
                                     needs no zero fill of these six arrays -- fdgs_deform_bwd, which runs afterwards, only ever adds to
                                     d_xyz (the HexPlane coordinate gradient) */
+    int tile_flags;              /* 1: G is followed by uint32 tile_live[Npad/32] (i.e. at (uint32_t*)(G + Npad*64)), written here:
+                                    tile_live[t] = 1 when any of the 32 packed rows 32t .. 32t+31 has a non-zero entry.  Culled, occluded and
+                                    off-screen Gaussians get all-zero rows (the reference gives them no gradient either,
+                                    gaussian_renderer/__init__.py:134-138); fdgs_deform_bwd (packed_rows_ready = 2) then skips whole tiles of
+                                    them -- bit-exact, a zero row adds exactly zero to every sum */
 } fdgs_raster_deform_epilogue;
 
 typedef struct fdgs_raster_grads {
@@ -224,7 +229,8 @@ typedef struct fdgs_deform_grads {
     /* opt: the `saved` buffer the forward of the SAME parameters / inputs filled (NULL: everything is recomputed) */
     const void* saved;
     /* 1: `scratch` already starts with the packed gradient rows and the identity paths were applied (fdgs_raster_bwd's epilogue);
-     * the g_* / out_* / rot_norm pointers above are then ignored */
+     * the g_* / out_* / rot_norm pointers above are then ignored.  2: as 1, and the rows are followed by the per-tile non-zero flags
+     * (fdgs_raster_deform_epilogue::tile_flags).  0: fdgs_deform_bwd packs the rows (and computes the flags) itself. */
     int packed_rows_ready;
     /* hint, never needed for correctness: 1 = consecutive Gaussians are spatial neighbours (the set is kept along a space-filling
      * curve, fdgs.densify.spatial_reorder): with one frame time for all Gaussians the plane gradient then runs as the windowed
@@ -235,6 +241,10 @@ typedef struct fdgs_deform_grads {
 
 int fdgs_deform_bwd_scratch_bytes(const fdgs_deform_params* p, size_t* bytes);
 int fdgs_deform_bwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_grads* g);
+/* Diagnostics (bench.py's FLOP accounting): after fdgs_deform_bwd on `scratch`, out_host[0] = 32-row tiles the backward processed
+ * (tiles with a non-zero packed gradient row, + at most 3 of padding), out_host[1] = tiles in total (Npad / 32),
+ * out_host[2] = plane-gradient chunks processed, out_host[3] = chunks in total.  Synchronises the stream. */
+int fdgs_deform_bwd_live_tiles(void* stream, const fdgs_deform_params* p, const void* scratch, uint32_t* out_host);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Loss-side helper for the frame-parallel driver: accumulates [sum|a-b|, sum (a-b)^2, n] into acc[3] (device,

@@ -119,6 +119,14 @@ class RasterOracle:
         nc = np.frombuffer((ctypes.c_char * (n * 4)).from_address(p), dtype=np.uint32).copy()
         return fT.reshape(self.H, self.W), nc.reshape(self.H, self.W)
 
+    def stage_tensors(self):
+        """The forward's stage values under the names tools/dump_cuda_golden.py::decode_stage_tensors uses for the upstream
+        extension's scratch buffers (tests/test_cuda_golden.py compares the two)."""
+        fT, nc = self.image_state()
+        return {"internal_radii": self.radii.copy(), "depths": self.field("depth"), "tiles_touched": self.field("tiles_touched").astype(np.uint32),
+                "means2D": self.field("xy"), "conic_opacity": self.field("conic_opacity"), "rgb": self.field("rgb"), "cov3D": self.field("cov3D"),
+                "num_rendered": int(self.num_rendered), "accum_alpha": fT.reshape(-1), "n_contrib": nc.reshape(-1)}
+
     def backward(self, dL_dcolor, dL_ddepth=None):
         dt, P = self.dtype, self.P
         dc = np.ascontiguousarray(np.asarray(dL_dcolor, dtype=dt)).reshape(3, self.H, self.W)

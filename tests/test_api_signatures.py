@@ -23,8 +23,9 @@ def _cases():
          None),   # gaussian_renderer/__init__.py:18 (its module imports the CUDA wheel: recorded list only)
         # GaussianModel methods: ours take the model as the first argument instead of self
         (D.add_densification_stats, ["pc", "viewspace_point_tensor", "update_filter", "radii=None"], None),
-        (D.prune_points, ["pc", "mask"], None),
-        (D.prune, ["pc", "max_grad", "min_opacity", "extent", "max_screen_size"], None),
+        # (trailing `reorder=None`: our optional extra -- back onto the Hilbert curve after the set was rebuilt)
+        (D.prune_points, ["pc", "mask", "reorder=None"], None),
+        (D.prune, ["pc", "max_grad", "min_opacity", "extent", "max_screen_size", "reorder=None"], None),
         (D.reset_opacity, ["pc"], None),
         (fdgs.compute_regulation, ["pc_or_net", "time_smoothness_weight", "l1_time_planes_weight", "plane_tv_weight"], None),
         (fdgs.io.save_ply, ["pc", "path"], None), (fdgs.io.save_deformation, ["pc", "path"], None),

@@ -64,3 +64,75 @@ def test_hip_rasterizer_matches_reference_cuda_output(path):
         for k, v in t.items():
             assert rel_l2(v.grad.cpu().numpy(), z[f"{variant}.grad.{k}"]) < 1e-3, (variant, k)
         assert rel_l2(m2d.grad.cpu().numpy(), z[f"{variant}.grad.means2D"]) < 1e-3
+
+
+def _stage_checks(z, tag, got):
+    """`got`: our stage tensors (same names as tools/dump_cuda_golden.py::decode_stage_tensors) for the same scene."""
+    vis = z[f"{tag}.internal_radii"] > 0
+    assert (got["internal_radii"] != z[f"{tag}.internal_radii"]).mean() < 2e-4
+    both = vis & (got["internal_radii"] > 0)
+    assert np.array_equal(got["tiles_touched"][both], z[f"{tag}.tiles_touched"][both])
+    assert np.abs(got["depths"][both] - z[f"{tag}.depths"][both]).max() < 1e-5
+    assert np.abs(got["means2D"].reshape(-1, 2)[both] - z[f"{tag}.means2D"].reshape(-1, 2)[both]).max() < 2e-3
+    assert rel_l2(got["conic_opacity"].reshape(-1, 4)[both], z[f"{tag}.conic_opacity"].reshape(-1, 4)[both]) < 1e-5
+    assert rel_l2(got["rgb"].reshape(-1, 3)[both], z[f"{tag}.rgb"].reshape(-1, 3)[both]) < 1e-5
+    assert rel_l2(got["cov3D"].reshape(-1, 6)[both], z[f"{tag}.cov3D"].reshape(-1, 6)[both]) < 1e-5
+    assert int(got["num_rendered"]) == int(z[f"{tag}.num_rendered"][0])
+    assert (got["n_contrib"] != z[f"{tag}.n_contrib"]).mean() < 1e-4 and np.abs(got["accum_alpha"] - z[f"{tag}.accum_alpha"]).mean() < 1e-6
+
+
+@need_files
+@pytest.mark.parametrize("path", FILES or ["-"])
+def test_oracle_stage_tensors_match_reference_cuda(path):
+    """Per-Gaussian and per-pixel STAGE values of the forward (what tests/test_gpu_raster.py compares HIP vs oracle) against the values
+    decoded from the upstream extension's scratch buffers; the `[1,4,4]` + debug=True call must give the same."""
+    from oracle.raster_oracle import RasterOracle
+    z = np.load(path)
+    if "stage.depths" not in z.files:
+        pytest.skip("golden file written by an older dump script (no stage tensors)")
+    o = RasterOracle(**_scene(z))
+    st = o.stage_tensors()
+    for tag in ("stage", "stage144"):
+        _stage_checks(z, tag, st)
+    assert np.array_equal(z["stage.color"], z["stage144.color"])
+
+
+@need_files
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES or ["-"])
+def test_hip_stage_tensors_match_reference_cuda(path, monkeypatch):
+    """Same for the HIP kernels, with the exact tile culling off (FDGS_TILE_CULL=0: the reference's pair lists, so tiles_touched,
+    num_rendered and n_contrib are comparable)."""
+    import ctypes
+    fd = importlib.import_module("4dgaussians_amd")
+    z = np.load(path)
+    if "stage.depths" not in z.files:
+        pytest.skip("golden file written by an older dump script (no stage tensors)")
+    monkeypatch.setenv("FDGS_TILE_CULL", "0")
+    dev = torch.device("cuda:0")
+    sc = _scene(z)
+    H, W, P = sc["image_height"], sc["image_width"], sc["means3D"].shape[0]
+    rs = fd.GaussianRasterizationSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.tensor(sc["bg"], device=dev), 1.0,
+                                          torch.tensor(sc["viewmatrix"], device=dev)[None], torch.tensor(sc["projmatrix"], device=dev)[None],
+                                          sc["sh_degree"], torch.tensor(sc["campos"], device=dev), False, True)      # ([1,4,4], debug=True)
+    t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    color, radii, depth, state = fd.rasterizer.rasterize_forward(rs, t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
+    L = fd._lib.lib()
+
+    def field(fn, buf, which, dtype, count, *a):
+        p = ctypes.c_void_p()
+        fd._lib.check(fn(fd._lib.ptr(buf), *a, which, ctypes.byref(p)))
+        off = p.value - buf.data_ptr()
+        return buf[off:off + count * np.dtype(dtype).itemsize].cpu().numpy().view(dtype)
+
+    recA = field(L.fdgs_geom_field, state.geom, 1, np.float32, 4 * P, P).reshape(P, 4)
+    recB = field(L.fdgs_geom_field, state.geom, 2, np.float32, 4 * P, P).reshape(P, 4)
+    recC = field(L.fdgs_geom_field, state.geom, 3, np.float32, 4 * P, P).reshape(P, 4)
+    got = {"internal_radii": radii.cpu().numpy(), "depths": field(L.fdgs_geom_field, state.geom, 0, np.float32, P, P),
+           "tiles_touched": field(L.fdgs_geom_field, state.geom, 5, np.uint32, P, P), "means2D": recA[:, :2].copy(),
+           "conic_opacity": np.concatenate([recA[:, 2:4], recB[:, 0:2]], 1), "rgb": recC[:, :3].copy(),
+           "cov3D": field(L.fdgs_geom_field, state.geom, 4, np.float32, 6 * P, P), "num_rendered": state.num_rendered,
+           "accum_alpha": field(L.fdgs_img_field, state.img, 0, np.float32, H * W, W, H),
+           "n_contrib": field(L.fdgs_img_field, state.img, 1, np.uint32, H * W, W, H)}
+    for tag in ("stage", "stage144"):
+        _stage_checks(z, tag, got)

@@ -451,3 +451,51 @@ def test_spatial_order_hint_selects_the_plane_gradient_kernel_not_the_result():
     xs = x[torch.argsort(keys)].contiguous()
     assert fd.deformation.spatial_order_hint(xs) is True
     assert fd.deformation.spatial_order_hint(xs[:100].contiguous()) is False        # too few rows to say
+
+
+@pytest.mark.parametrize("cfg,n,ordered", [("dynerf_default", 9000, True), ("dynerf_default", 9000, False), ("hypernerf_default", 5000, True),
+                                           ("dnerf_bouncingballs", 7000, True)])
+def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
+    """Culled / occluded Gaussians arrive with all-zero gradient rows (gaussian_renderer/__init__.py:134-138: they get no gradient in
+    the reference either); in a spatially ordered set they are contiguous, and the backward walks only the 32-row tiles that carry a
+    non-zero row (tile_compact_kernel's lists).  With runs of zero upstream rows whose ends are NOT tile-aligned, every gradient must
+    equal the FDGS_SKIP_DEAD=0 result (all tiles) up to the re-association of the sums, and fewer tiles must have been processed."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs(cfg, n, 5, dev, safe=False, fixed_time=0.43)
+    net = net.to(dev)
+    mask = torch.ones(n)
+    for a, b in ((0, 1000), (1033, 2977), (3100, 3131), (4000, n - 700)):
+        mask[a:b] = 0.0
+    ws = [torch.randn(s, generator=torch.Generator().manual_seed(2)) for s in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 16, 3))]
+    ws = [(w * mask.reshape([-1] + [1] * (w.dim() - 1))).to(dev) for w in ws]
+    monkeypatch.setattr(fd.deformation, "COUNT_LIVE_TILES", True)
+    res = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("FDGS_SKIP_DEAD", skip)
+        gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
+        out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.43, activate=True, ordered=ordered)
+        params = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
+        g = torch.autograd.grad(sum((o * w).sum() for o, w in zip(out, ws)), gpu_in[:5] + [p for _, p in params], allow_unused=True)
+        torch.cuda.synchronize()
+        res[skip] = (g, fd.deformation.last_live_tiles)
+    names = ["xyz", "scales", "rot", "opacity", "shs"] + [k for k, _ in params]
+    live, total = res["1"][1][0], res["1"][1][1]
+    print(f"[{cfg} n={n} ordered={ordered}] live tiles {live} of {total}; chunks {res['1'][1][2]} of {res['1'][1][3]}")
+    assert res["0"][1][0] == res["0"][1][1] == total
+    expect = len({i // 32 for i in torch.nonzero(mask).squeeze(1).tolist()})
+    assert expect <= live <= expect + 3 and live < 0.5 * total
+    worst = {}
+    for k, a, b in zip(names, res["1"][0], res["0"][0]):
+        if b is None:
+            assert a is None
+            continue
+        worst[k] = rel_l2(a.cpu().numpy(), b.cpu().numpy())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print("   skip vs no-skip worst rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in top))
+    for k, v in worst.items():
+        assert v < 2e-6, (k, v)
+    # rows without an upstream gradient receive exactly the identity-path zeros in both runs
+    dead = (mask == 0).to(dev)
+    for a in res["1"][0][:5]:
+        assert float(a[dead].abs().max()) == 0.0

@@ -15,6 +15,15 @@ from test_oracle_densify import GOLD, assert_states_equal, load_state
 pytestmark = pytest.mark.gpu
 fdgs = importlib.import_module("4dgaussians_amd")
 dn = importlib.import_module("4dgaussians_amd.densify")
+
+
+@pytest.fixture(autouse=True)
+def _reference_row_order(monkeypatch):
+    """These tests compare ROW ORDER with the reference's clone -> split -> prune sequence: the automatic re-ordering along the
+    Hilbert curve (semantically free, on by default) is switched off here and tested on its own below."""
+    monkeypatch.setattr(dn, "AUTO_REORDER", False)
+
+
 ATTR = dn.ATTR
 
 
@@ -147,3 +156,25 @@ def test_stats_kernel_against_boolean_indexing():
         DO.add_densification_stats(st, vg, vis, radii)
     assert torch.equal(m.denom.cpu(), st["denom"]) and torch.equal(m.max_radii2D.cpu(), st["max_radii2D"])
     assert (m.xyz_gradient_accum.cpu() - st["xyz_gradient_accum"]).abs().max().item() < 1e-8
+
+
+def test_densify_reorders_the_grown_set_along_the_curve(monkeypatch):
+    """With AUTO_REORDER (the default) densify() leaves the grown set in Hilbert order -- the order bench.py measures and the
+    deformation kernels are tuned for -- and the result is the reference-order result up to that permutation: same multiset of rows in
+    every Parameter, Adam moment and side array."""
+    st = DO.random_state(5000, seed=3, sh_rest=15)
+    normals = torch.randn(2 * 5000, 3, generator=torch.Generator().manual_seed(1))
+    a, b = model_from_state(st), model_from_state(st)
+    ra = dn.densify(a, 0.0002, 0.005, 3.0, 20, normals=normals.cuda(), reorder=False)
+    monkeypatch.setattr(dn, "AUTO_REORDER", True)
+    rb = dn.densify(b, 0.0002, 0.005, 3.0, 20, normals=normals.cuda())
+    assert ra == rb and ra[1] + ra[2] > 0
+    assert fdgs.deformation.spatial_order_hint(b._xyz) is True
+    keys_a = dn.hilbert_keys(a._xyz)
+    perm = torch.argsort(keys_a, stable=True)
+    for n in DO.GROUPS:
+        pa, pb = getattr(a, ATTR[n]).detach()[perm], getattr(b, ATTR[n]).detach()
+        assert torch.equal(pa, pb), n
+        sa, sb = a.optimizer.state[getattr(a, ATTR[n])], b.optimizer.state[getattr(b, ATTR[n])]
+        assert torch.equal(sa["exp_avg"][perm], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"][perm], sb["exp_avg_sq"])
+    assert torch.equal(a._deformation_table[perm], b._deformation_table)

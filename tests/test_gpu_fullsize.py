@@ -1,4 +1,4 @@
-"""Parity at the sizes the headline is quoted on (BASELINE.json configs 2, 3, 4): render() forward + backward through the HIP
+"""Parity at the sizes the headline is quoted on (BASELINE.json configs 2, 3, 4, 5): render() forward + backward through the HIP
 path against the oracle chain on the SAME frame -- image, depth, radii, every Gaussian-parameter gradient, every HexPlane and
 MLP gradient, the view-space gradient.  The small-size tests exercise one tile round per CU; these run the persistent tile
 loops (9 rounds per CU), the cost-model work split of the weight-gradient kernel, the LDS-privatised time planes at full
@@ -21,6 +21,9 @@ CONFIGS = {
     "cfg2_dnerf_100k_800x800": (100_000, 800, 800, "dnerf_bouncingballs"),
     "cfg3_hypernerf_300k_536x960": (300_000, 536, 960, "hypernerf_default"),
     "cfg4_dynerf_300k_1352x1014": (300_000, 1352, 1014, "dynerf_default"),
+    # BASELINE.json configs[4]: the 2 M / 2048^2 stress case -- multi-chunk scans, a 23 M-pair sort, 16 384 tiles, 62 500 backward tiles,
+    # > 4 GB of saved activations; the oracle chain takes ~1 minute of host time
+    "cfg5_stress_2M_2048x2048": (2_000_000, 2048, 2048, "dynerf_default"),
 }
 
 
@@ -57,8 +60,14 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     dmean = float(np.abs(res["depth"].detach().cpu().numpy() - o.depth).mean())
     radii = res["radii"].cpu().numpy()
     mism = float((radii != o.radii).mean())
-    print(f"[{name}] visible {(o.radii > 0).sum()}  image psnr {psnr:.1f} dB  max|dC| {d.max():.2e}  mean {d.mean():.2e}  depth mean abs {dmean:.2e}  radii mismatch {mism:.2e}")
+    # isolated pixels where a 1/255 / T < 1e-4 decision falls the other way in float rounding: counted and bounded, not hidden in the mean
+    n_flip = int((d.max(axis=0) > 1e-4).sum())
+    print(f"[{name}] visible {(o.radii > 0).sum()}  image psnr {psnr:.1f} dB  max|dC| {d.max():.2e}  mean {d.mean():.2e}  pixels over 1e-4: {n_flip} of {H * W}  "
+          f"depth mean abs {dmean:.2e}  radii mismatch {mism:.2e}")
     assert psnr >= 80.0 and d.mean() < 2e-6
+    # measured: 18 .. 958 such pixels (0.003 % .. 0.07 %); each is ONE alpha >= 1/255 decision taken the other way for an entry
+    # whose alpha sits within rounding of the threshold, which moves a pixel by at most alpha * T * colour <= ~1/255
+    assert n_flip <= int(2e-3 * H * W) and d.max() <= 1.1 / 255.0, (n_flip, float(d.max()))
     assert dmean < 2e-5 and mism < 2e-4
     named = dict(pc.named_parameters())
     rep = {}

@@ -276,3 +276,31 @@ def test_render_views_equals_per_view_render_with_summed_loss(nviews):
     assert worst[0] < 2e-5
     for v in range(nviews):
         assert rel_l2(va[v].cpu().numpy(), res_b[v]["viewspace_points"].grad.cpu().numpy()) < 1e-6
+
+
+def test_backward_skips_tiles_the_rasterizer_gave_no_gradient(monkeypatch):
+    """A camera that sees well under half of a spatially ordered set: the Gaussians outside the frustum (and the occluded ones) get
+    all-zero rows from fdgs_raster_bwd's epilogue, which also leaves the per-tile flags; the deformation backward then walks only the
+    live tiles.  Gradients must equal the all-tiles run (FDGS_SKIP_DEAD=0) to the re-association of the sums."""
+    fd = _fd()
+    dev = torch.device("cuda:0")
+    pc = synthetic.SynthModel(40_000, "dynerf_default", seed=23)
+    fd.densify.spatial_reorder(pc)
+    pc = pc.to(dev)
+    cam = synthetic.make_camera(320, 240, theta_deg=20.0, time=0.6, radius=1.2).to(dev)     # inside the cloud: most of it is behind / beside the camera
+    w = torch.randn(3, 240, 320, generator=torch.Generator().manual_seed(4)).to(dev)
+    monkeypatch.setattr(fd.deformation, "COUNT_LIVE_TILES", True)
+    runs = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("FDGS_SKIP_DEAD", skip)
+        res, g, v = _render_and_grads(pc, cam, _Pipe(), "fine", w)
+        runs[skip] = (res, g, v, fd.deformation.last_live_tiles)
+    vis = float((runs["1"][0]["radii"] > 0).float().mean())
+    live, total = runs["1"][3][0], runs["1"][3][1]
+    print(f"visible {vis:.2f} of the set; live tiles {live} of {total}")
+    assert 0.02 < vis < 0.6 and live < 0.6 * total and runs["0"][3][0] == total
+    assert torch.equal(runs["1"][0]["render"], runs["0"][0]["render"])
+    for k in runs["0"][1]:
+        e = rel_l2(runs["1"][1][k].cpu().numpy(), runs["0"][1][k].cpu().numpy())
+        assert e < 2e-6, (k, e)
+    assert rel_l2(runs["1"][2].cpu().numpy(), runs["0"][2].cpu().numpy()) < 2e-6      # (blending atomics: order differs run to run)

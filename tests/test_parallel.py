@@ -189,3 +189,75 @@ def test_two_gpu_ranks_meet_over_rccl(tmp_path):
     for r in range(2):
         rank, world, seen, times, calls, ga, gb, dev = eval(open(f"{path}.{r}").read())
         assert (rank, world, seen) == (r, 2, 2) and ga == [3.0] * 5 and gb == [7.0] * 3 and dev == f"cuda:{r}"
+
+
+# ---- bench.py's rank logic end to end with a stub step (no GPU): camera assignment over steps x world, timed regions reduced with
+# MAX over ranks, ranks_seen, per-rank figures, rank-0-only JSON line ----
+def _bench_stub_rank(path, steps, warmup, repeats):
+    import importlib.util as ilu
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = ilu.spec_from_file_location("bench_stub_mod", os.path.join(root, "bench.py"))
+    bench = ilu.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import argparse
+    import contextlib
+    import io
+    args = argparse.Namespace(gpus=2, steps=steps, warmup=warmup, repeats=repeats)
+
+    def make_step(ctx):
+        def step(i, cam):
+            time.sleep(0.002 * (1 + 2 * ctx["rank"]))       # rank 1 is three times slower: MAX over ranks must report it
+        return step
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = bench.run(args, make_step=make_step)
+    with open(f"{path}.{out['cameras_rank_local'][0] % 2}", "w") as f:
+        f.write(repr((out, buf.getvalue())))
+
+
+def test_bench_rank_logic_with_a_stub_step(tmp_path):
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    steps, warmup, repeats = 6, 2, 3
+    path = str(tmp_path / "b")
+    par.spawn_local(2, _bench_stub_rank, (path, steps, warmup, repeats))
+    res = [eval(open(f"{path}.{r}").read()) for r in range(2)]
+    import importlib.util as ilu
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = ilu.spec_from_file_location("bench_plan_mod", os.path.join(root, "bench.py"))
+    bench = ilu.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = bench.rank_plan(160, steps, warmup, repeats, 2)
+    for r, (out, printed) in enumerate(res):
+        assert out["cameras_rank_local"] == plan[r]                       # rank r renders camera (step * world + r) mod n
+        assert out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["timed_regions"] == repeats
+        assert len(out["per_rank_ms_per_step"]) == 2 and len(out["startup_s_per_rank"]) == 2
+        # both ranks report the same (MAX over ranks) time, and it is the slow rank's: >= 6 ms per step
+        assert out["ms_per_step"] >= 5.5 and out["per_rank_ms_per_step"][1] > 2.0 * out["per_rank_ms_per_step"][0]
+        assert abs(out["value"] - 2 * steps / (out["ms_per_step"] * steps / 1e3)) < 1e-6     # whole-job frames/s over all ranks
+        if r == 0:
+            line = json.loads(printed.strip())                            # exactly one JSON line, on rank 0 only
+            assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warmup
+        else:
+            assert printed.strip() == ""
+    assert res[0][0]["ms_per_step"] == res[1][0]["ms_per_step"]
+    every = sorted(res[0][0]["cameras_rank_local"] + res[1][0]["cameras_rank_local"])
+    assert every == list(range(2 * warmup, 2 * warmup + 2 * steps * repeats))     # each frame of the orbit rendered exactly once
+
+
+def _one_rank_dies_the_other_waits():
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    rank, world, dev = par.init_from_env(backend="gloo")
+    if rank == 1:
+        raise SystemExit(5)
+    par.barrier()           # rank 0 would sit here until the process-group timeout
+
+
+def test_spawn_local_terminates_siblings_of_a_dead_rank():
+    import time
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match="exited non-zero"):
+        par.spawn_local(2, _one_rank_dies_the_other_waits)
+    assert time.monotonic() - t0 < 60.0        # (not the process-group timeout of minutes)

@@ -8,7 +8,9 @@ the reference, `pip install submodules/depth-diff-gaussian-rasterization`, NVIDI
 
 It renders the seeded scenes below with the upstream `diff_gaussian_rasterization` (forward + backward, with and without a
 depth gradient, SH and precomputed-colour / precomputed-covariance variants) and writes tests/golden/raster_cuda_<case>.npz:
-every input, image, depth, radii and every gradient.  Commit those files: tests/test_cuda_golden.py consumes them when
+every input, image, depth, radii and every gradient, plus the STAGE tensors of the forward (per-Gaussian depth / radius / 2-D mean /
+cov3D / conic+opacity / rgb / tiles_touched, per-pixel final T and n_contrib, num_rendered -- decoded from the extension's scratch
+buffers) for the plain call and for the `[1,4,4]`-matrices + debug=True call of scene/dataset_readers.py:485-508.  Commit those files: tests/test_cuda_golden.py consumes them when
 present -- the CPU leg pins oracle/raster_oracle.c to them, the GPU leg compares the HIP rasterizer with them directly.
 The seeded scenes come from tests/scenes.py (torch-CPU / numpy; libfdgs.so is NOT needed), so a bare checkout of this repo
 next to the upstream wheel is enough.
@@ -32,6 +34,37 @@ CASES = {
     "deg0_culled_5k": dict(n=5000, width=320, height=240, seed=3, theta=0.0, sh_degree=0, extent=3.0),
     "cfg2_100k_800": dict(n=100000, width=800, height=800, seed=11, theta=100.0, scale_boost=2.0),
 }
+
+
+def _carve(buf, fields, n_of):
+    """Upstream scratch buffers are carved field by field with 128-byte alignment (`obtain(chunk, ptr, count, 128)` in
+    rasterizer_impl's GeometryState / ImageState ::fromChunk).  fields: (name, dtype, count-expression).  Returns {name: array} and the
+    number of bytes consumed.  The layout below is restated from the published upstream source [from memory -- the raw buffers are
+    dumped too, so a differing fork revision can be re-decoded later without a CUDA box]."""
+    out, off = {}, 0
+    base = buf.ctypes.data
+    for name, dt, cnt in fields:
+        addr = (base + off + 127) // 128 * 128
+        off = addr - base
+        n = n_of(cnt)
+        nbytes = n * np.dtype(dt).itemsize
+        if off + nbytes > buf.size:
+            return out, off       # (layout assumption broke: keep what decoded so far)
+        out[name] = np.frombuffer(buf, dtype=dt, count=n, offset=off).copy()
+        off += nbytes
+    return out, off
+
+
+def decode_stage_tensors(geom, img, P, H, W):
+    """Stage tensors the HIP tests compare (tests/test_gpu_raster.py): depths, clamped, radii, means2D, cov3D, conic_opacity, rgb,
+    tiles_touched from the geometry buffer; accum_alpha (= final T), n_contrib from the image buffer."""
+    g, _ = _carve(geom, [("depths", np.float32, "P"), ("clamped", np.bool_, "3P"), ("internal_radii", np.int32, "P"),
+                         ("means2D", np.float32, "2P"), ("cov3D", np.float32, "6P"), ("conic_opacity", np.float32, "4P"),
+                         ("rgb", np.float32, "3P"), ("tiles_touched", np.uint32, "P")],
+                  lambda c: {"P": P, "2P": 2 * P, "3P": 3 * P, "4P": 4 * P, "6P": 6 * P}[c])
+    i, _ = _carve(img, [("accum_alpha", np.float32, "N"), ("n_contrib", np.uint32, "N")], lambda c: H * W)
+    g.update(i)
+    return g
 
 
 def upstream_module():
@@ -82,6 +115,27 @@ def main():
                         f"{variant}.grad.means2D": m2d.grad.cpu().numpy()})
             for k, v in t.items():
                 out[f"{variant}.grad.{k}"] = v.grad.cpu().numpy()
+        # ---- stage tensors: the upstream extension called directly (the call `_RasterizeGaussians.forward` makes,
+        # gaussian_renderer/__init__.py:120-128), once more with the [1,4,4] matrices and debug=True of the second construction
+        # site (scene/dataset_readers.py:485-508) -- results must not depend on either
+        with torch.no_grad():
+            for tag, vm, pm, dbg in (("stage", torch.tensor(sc["viewmatrix"], device=dev), torch.tensor(sc["projmatrix"], device=dev), False),
+                                     ("stage144", torch.tensor(sc["viewmatrix"], device=dev)[None], torch.tensor(sc["projmatrix"], device=dev)[None], True)):
+                res = dgr._C.rasterize_gaussians(torch.tensor(sc["bg"], device=dev), t["means3D"].detach(), torch.Tensor([]).to(dev), t["opacities"].detach(),
+                                                 t["scales"].detach(), t["rotations"].detach(), 1.0, torch.Tensor([]).to(dev), vm, pm, sc["tanfovx"], sc["tanfovy"],
+                                                 sc["image_height"], sc["image_width"], t["shs"].detach(), sc["sh_degree"], torch.tensor(sc["campos"], device=dev),
+                                                 False, dbg)
+                res = list(res)
+                num_rendered = int(res[0])
+                bufs = [r for r in res[1:] if r.dtype == torch.uint8]            # geomBuffer, binningBuffer, imgBuffer (in this order)
+                imgs = [r for r in res[1:] if r.dtype in (torch.float32, torch.int32)]
+                out[f"{tag}.num_rendered"] = np.array([num_rendered], np.int64)
+                out[f"{tag}.color"] = imgs[0].cpu().numpy()
+                geom, imgb = bufs[0].cpu().numpy(), bufs[-1].cpu().numpy()
+                for k, v in decode_stage_tensors(geom, imgb, sc["means3D"].shape[0], sc["image_height"], sc["image_width"]).items():
+                    out[f"{tag}.{k}"] = v
+                if tag == "stage" and sc["means3D"].shape[0] <= 20000:      # raw bytes of the small cases: re-decodable without a CUDA box
+                    out["stage.raw_geomBuffer"], out["stage.raw_imgBuffer"] = geom, imgb
         path = os.path.join(args.out, f"raster_cuda_{name}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path))

@@ -16,7 +16,7 @@ if [ -z "$SKIP_BENCH" ]; then
 fi
 prof_one() {  # $1 = workload, $2 = suffix
   cd /tmp && export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof$2 -o trace --output-format csv -- python $R/bench.py --workload $1 --steps 20 --warmup 4 --repeats 1 --no-cpu-baseline --no-train-step > $R/gpurun_out/${TAG}_prof_bench$2.json 2> $R/gpurun_out/${TAG}_prof$2.err
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof$2 -o trace --output-format csv -- python $R/bench.py --workload $1 --steps 20 --warmup 4 --repeats 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_prof_bench$2.json 2> $R/gpurun_out/${TAG}_prof$2.err
   cd $R
   python - <<PY
 import csv, glob
@@ -33,7 +33,7 @@ PY
 pmc_one() {  # $1 = workload, $2 = suffix: FETCH_SIZE and WRITE_SIZE in separate passes (TCC counters do not fit one pass)
   cd /tmp && export TMPDIR=/tmp
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 240 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_pmc_${C}$2 -o pmc --output-format csv -- python $R/bench.py --workload $1 --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1
+    timeout 240 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_pmc_${C}$2 -o pmc --output-format csv -- python $R/bench.py --workload $1 --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   done
   cd $R
   ST=gpurun_out/${TAG}_kernel_stats$2.txt
@@ -43,14 +43,15 @@ WL0=cfg4_dynerf_300k_1352x1014
 if [ -z "$SKIP_PROF" ]; then prof_one $WL0 ""; fi
 if [ -n "$PMC" ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq -o pmc --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq -o pmc --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   cd $R
   python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq gpurun_out/${TAG}_pmc_sq.txt > /dev/null
   head -8 gpurun_out/${TAG}_pmc_sq.txt | cut -c1-230
   pmc_one $WL0 ""
 fi
 for WL in $EXTRA_WORKLOADS; do
-  timeout 300 python bench.py --workload $WL --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_$WL.json 2> gpurun_out/${TAG}_bench_$WL.err
+  # (one CPU frame: every workload's line carries its own parity against the oracle chain)
+  timeout 600 python bench.py --workload $WL --steps 10 --warmup 3 --repeats 5 --cpu-frames 1 > gpurun_out/${TAG}_bench_$WL.json 2> gpurun_out/${TAG}_bench_$WL.err
   python -c "
 import json,sys
 d=json.load(open('gpurun_out/${TAG}_bench_$WL.json')); print('$WL', round(d['value'],1), 'frames/s', d['config']['num_rendered'], d['kernels_ms_per_step'])" 2>&1 | cut -c1-500

@@ -62,7 +62,7 @@ def main():
         fe, wr = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
     res = {"_workload": workload, "_src_sha16": src_sha16(),
            "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --workload "
-                      + workload + " --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-train-step, MI355X",
+                      + workload + " --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras, MI355X",
            "_units": "KB per launch as reported by rocprofv3 (TCC_EA0 request counters x 64 B); gfx950 reports HALF of the bytes of "
                      "16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section): consumers double FETCH_SIZE"}
     dur = {}
