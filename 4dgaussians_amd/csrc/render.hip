@@ -21,6 +21,33 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
     return ((b >> 3) < chunk && tile < ntiles) ? tile : -1;
 }
 
+// The exponent of a blended Gaussian, written so that EVERY kernel that evaluates it rounds it the same way (the forward decides
+// alpha >= 1/255 and T < 1e-4 from it, the backward has to take the same decisions): -0.5 * (dx*(dx*cxx) + dy*(dy*cyy)) - dy*(dx*cxy),
+// products and the sum rounded separately, one fused multiply-add at the end.
+__device__ __forceinline__ float blend_power_xx(float cxx, float dx) {
+#pragma clang fp contract(off)
+    return dx * (dx * cxx);
+}
+__device__ __forceinline__ float blend_power_xy(float cxy, float dx) {
+#pragma clang fp contract(off)
+    return dx * cxy;
+}
+__device__ __forceinline__ float blend_power(float u1, float cx, float cyy, float dy) {
+#pragma clang fp contract(off)
+    const float u2 = dy * (dy * cyy);
+    const float c2 = dy * cx;
+    const float q = u1 + u2;
+    return __builtin_fmaf(q, -0.5f, -c2);
+}
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_ blend_power2(float u1, float cx, float cyy, v2f_ dy) {
+#pragma clang fp contract(off)
+    const v2f_ u2 = dy * (dy * cyy);
+    const v2f_ c2 = dy * cx;
+    const v2f_ q = u1 + u2;
+    return __builtin_elementwise_fma(q, v2f_{-0.5f, -0.5f}, -c2);
+}
+
 struct RenderArgs {
     int W, H, gx, gy;
     const uint2* ranges; const uint32_t* pair_gid;
@@ -58,7 +85,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
             const float4 A = sA[j];
             const float4 B = sB[j];
             const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float power = blend_power(blend_power_xx(A.z, dx), blend_power_xy(A.w, dx), B.x, dy);
             if (power > 0.0f) continue;
             const float alpha = fminf(FDGS_ALPHA_MAX, B.y * __expf(power));
             if (alpha < FDGS_ALPHA_MIN) continue;
@@ -187,7 +214,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
             const float4 A = sA[j];
             const float4 B = sB[j];
             const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float power = blend_power(blend_power_xx(A.z, dx), blend_power_xy(A.w, dx), B.x, dy);
             const float G = __expf(power);
             const float alpha = fminf(FDGS_ALPHA_MAX, B.y * G);
             const bool valid = (ej < last_contributor) && !(power > 0.0f) && !(alpha < FDGS_ALPHA_MIN);
@@ -268,6 +295,274 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
     }
 }
 
+// ---- K7, strip form (round 3): ONE wave per workgroup, PPL pixels per lane ------------------------------------------------------
+// The 256-thread form above is bound by VALU issue (a wave64 instruction holds its SIMD for four cycles): ~125 instructions per
+// (wave, entry), of which ~50 are the cross-lane reduction of the nine per-Gaussian sums and ~15 the per-entry overhead -- paid once
+// per 64 pixels.  Here a wave owns a 16 x (4*PPL) pixel strip of the tile, lane = (x, y0) with PPL pixels y0, y0+4, ... below each other:
+//   * the lane's pixels share dx, so the per-Gaussian sums are first formed PER LANE as moments over dy (V0 = sum v, V1 = sum v*dy,
+//     V2 = sum v*dy^2 with v = G * dL_dalpha) and turned into the six geometric sums once per lane, not once per pixel;
+//   * the cross-lane reduction and the atomic line-op are paid once per 64*PPL pixels;
+//   * the blending recurrences run branch-free (an invalid pixel blends alpha = 0, which leaves T and the running colour exactly
+//     unchanged), in the un-lagged form acc' = alpha*c + (1-alpha)*acc (the same expression the lagged reference form evaluates one
+//     entry later);
+//   * a wave is its own workgroup: it stages its own 64 entries per round (records prefetched one round ahead, list ids two), never
+//     waits for another wave, and sends its sums straight to the gradient line (lanes 0..NV-1, one atomic instruction per entry).
+__device__ __forceinline__ int unit_of_block(int b, int nunits) {
+    const int chunk = (nunits + 7) >> 3;
+    const int u = (b & 7) * chunk + (b >> 3);
+    return ((b >> 3) < chunk && u < nunits) ? u : -1;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
+
+// PPL = 2 * NP pixels per lane, held as NP float2 pairs so that the per-pixel arithmetic issues as v_pk_{mul,add,fma}_f32
+template <bool DEPTH, int NP>
+__global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
+    constexpr int PPL = 2 * NP;
+    constexpr int PARTS = 4 / PPL;
+    constexpr int NV = DEPTH ? 10 : 9;
+    const int unit = unit_of_block(blockIdx.x, a.gx * a.gy * PARTS);
+    if (unit < 0) return;
+    const int tile = unit / PARTS, part = unit - tile * PARTS;
+    __shared__ float4 sA[64], sB[64], sC[64];
+    __shared__ uint32_t sGid[64];
+    const int lane = threadIdx.x;
+    const int x = (tile % a.gx) * TILE + (lane & 15);
+    const int y0 = (tile / a.gx) * TILE + part * (4 * PPL) + (lane >> 4);
+    const float pxf = (float)x;
+    const size_t hw = (size_t)a.H * a.W;
+    const uint2 range = a.ranges[tile];
+    v2f py[NP], T[NP], tfb[NP], dp0[NP], dp1[NP], dp2[NP], ddep[NP], acc0[NP], acc1[NP], acc2[NP], accd[NP];
+    uint32_t lastc[PPL];
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const int y = y0 + 4 * i;
+        const bool inside = x < a.W && y < a.H;
+        const size_t pix = (size_t)y * a.W + x;
+        const int p = i >> 1, c = i & 1;
+        py[p][c] = (float)y;
+        T[p][c] = inside ? a.final_T[pix] : 0.f;
+        lastc[i] = inside ? a.n_contrib[pix] : 0u;
+        dp0[p][c] = inside ? a.dL_dcolor[pix] : 0.f;
+        dp1[p][c] = inside ? a.dL_dcolor[hw + pix] : 0.f;
+        dp2[p][c] = inside ? a.dL_dcolor[2 * hw + pix] : 0.f;
+        ddep[p][c] = (DEPTH && inside) ? a.dL_ddepth[pix] : 0.f;
+        m = lastc[i] > m ? lastc[i] : m;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        tfb[p] = -T[p] * (a.bg[0] * dp0[p] + a.bg[1] * dp1[p] + a.bg[2] * dp2[p]);
+        acc0[p] = acc1[p] = acc2[p] = accd[p] = splat2(0.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+    const int todo = (int)m;             // the strip only ever needs the first max(n_contrib) entries of the tile's list
+    if (todo == 0) return;
+    const int rounds = (todo + 63) >> 6;
+    // staging pipeline: list ids two rounds ahead, records one round ahead (the records' addresses depend on the ids)
+    auto gid_of = [&](int r) -> uint32_t {
+        const int e = todo - 1 - (r * 64 + lane);
+        return a.pair_gid[range.x + (e >= 0 ? e : 0)];
+    };
+    uint32_t g_cur = gid_of(0), g_nxt = rounds > 1 ? gid_of(1) : 0u;
+    float4 rA = a.recA[g_cur], rB = a.recB[g_cur], rC = a.recC[g_cur];
+    for (int r = 0; r < rounds; r++) {
+        __syncthreads();                 // (one wave: orders the previous round's LDS reads before these writes)
+        sGid[lane] = g_cur; sA[lane] = rA; sB[lane] = rB; sC[lane] = rC;
+        __syncthreads();
+        if (r + 1 < rounds) { g_cur = g_nxt; rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
+        if (r + 2 < rounds) g_nxt = gid_of(r + 2);
+        const int rem = todo - r * 64;
+        const int lim = rem < 64 ? rem : 64;
+        for (int j = 0; j < lim; j++) {
+            const uint32_t ej = (uint32_t)(todo - 1 - (r * 64 + j));
+            const float4 A = sA[j];
+            const float4 B = sB[j];
+            const float dx = A.x - pxf;
+            v2f dy[NP], G[NP], alpha[NP];
+            bool valid[PPL], any = false;
+            {
+                const float u1 = blend_power_xx(A.z, dx);
+                const float cx = blend_power_xy(A.w, dx);
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    dy[p] = splat2(A.y) - py[p];
+                    const v2f power = blend_power2(u1, cx, B.x, dy[p]);
+                    G[p][0] = __expf(fminf(power[0], 0.0f));      // (power > 0 is invalid below; the clamp only keeps G finite)
+                    G[p][1] = __expf(fminf(power[1], 0.0f));
+                    alpha[p] = B.y * G[p];
+                    alpha[p][0] = fminf(FDGS_ALPHA_MAX, alpha[p][0]);
+                    alpha[p][1] = fminf(FDGS_ALPHA_MAX, alpha[p][1]);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        valid[2 * p + c] = (ej < lastc[2 * p + c]) && !(power[c] > 0.0f) && !(alpha[p][c] < FDGS_ALPHA_MIN);
+                        any = any || valid[2 * p + c];
+                    }
+                }
+            }
+            if (!__any(any)) continue;
+            const float4 Cc = sC[j];
+            v2f V0 = splat2(0.f), V1 = V0, V2 = V0, gc0 = V0, gc1 = V0, gc2 = V0, gd = V0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                v2f al;
+                al[0] = valid[2 * p] ? alpha[p][0] : 0.f;
+                al[1] = valid[2 * p + 1] ? alpha[p][1] : 0.f;
+                // 1/(1-alpha) once (v_rcp_f32 + one Newton step, <= 1 ulp) for both divisions of the reference formula
+                const v2f om = splat2(1.0f) - al;
+                v2f inv;
+                inv[0] = __builtin_amdgcn_rcpf(om[0]); inv[1] = __builtin_amdgcn_rcpf(om[1]);
+                inv = fma2(fma2(-om, inv, splat2(1.0f)), inv, inv);
+                T[p] = T[p] * inv;
+                const v2f w = al * T[p];
+                v2f dLda = fma2(splat2(Cc.z) - acc2[p], dp2[p], fma2(splat2(Cc.y) - acc1[p], dp1[p], (splat2(Cc.x) - acc0[p]) * dp0[p]));
+                if (DEPTH) {
+                    dLda = fma2(splat2(B.z) - accd[p], ddep[p], dLda);
+                    accd[p] = fma2(al, splat2(B.z), om * accd[p]);
+                    gd = fma2(w, ddep[p], gd);
+                }
+                acc0[p] = fma2(al, splat2(Cc.x), om * acc0[p]);
+                acc1[p] = fma2(al, splat2(Cc.y), om * acc1[p]);
+                acc2[p] = fma2(al, splat2(Cc.z), om * acc2[p]);
+                gc0 = fma2(w, dp0[p], gc0); gc1 = fma2(w, dp1[p], gc1); gc2 = fma2(w, dp2[p], gc2);
+                dLda = fma2(dLda, T[p], tfb[p] * inv);
+                v2f v = G[p] * dLda;
+                v[0] = valid[2 * p] ? v[0] : 0.f;
+                v[1] = valid[2 * p + 1] ? v[1] : 0.f;
+                const v2f vy = v * dy[p];
+                V0 += v; V1 += vy; V2 = fma2(vy, dy[p], V2);
+            }
+            // the lane's six geometric sums from its moments over dy (dL_dG * G = opacity * v)
+            const float u0 = B.y * (V0[0] + V0[1]), u1 = B.y * (V1[0] + V1[1]), u2 = B.y * (V2[0] + V2[1]);
+            const float ux = u0 * dx;
+            float g_mx = -(A.z * ux + A.w * u1), g_my = -(B.x * u1 + A.w * ux);
+            float g_cxx = -0.5f * ux * dx, g_cxy = -0.5f * u1 * dx, g_cyy = -0.5f * u2;
+            float g_op = V0[0] + V0[1];
+            float g_c0 = gc0[0] + gc0[1], g_c1 = gc1[0] + gc1[1], g_c2 = gc2[0] + gc2[1], g_d = gd[0] + gd[1];
+            g_mx = row_allsum(g_mx); g_my = row_allsum(g_my);
+            g_cxx = row_allsum(g_cxx); g_cxy = row_allsum(g_cxy); g_cyy = row_allsum(g_cyy);
+            g_op = row_allsum(g_op);
+            g_c0 = row_allsum(g_c0); g_c1 = row_allsum(g_c1); g_c2 = row_allsum(g_c2);
+            if (DEPTH) g_d = row_allsum(g_d);
+            const int sub = lane & 15;
+            float v = g_mx;
+            v = sub == 1 ? g_my : v; v = sub == 2 ? g_cxx : v; v = sub == 3 ? g_cxy : v; v = sub == 4 ? g_cyy : v;
+            v = sub == 5 ? g_op : v; v = sub == 6 ? g_c0 : v; v = sub == 7 ? g_c1 : v; v = sub == 8 ? g_c2 : v;
+            if (DEPTH) v = sub == 9 ? g_d : v;
+            {
+                auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            {
+                auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            }
+            if (lane < NV && v != 0.f) atomicAdd(&a.gacc[(size_t)sGid[j] * 16 + lane], v);
+        }
+    }
+}
+
+// ---- K6, strip form (round 3): the forward counterpart of render_bwd_strip_kernel -- one wave per 16 x (8*NP) pixel strip, NP float2
+// pixel pairs per lane sharing dx, branch-free blending (a pixel that skips an entry blends w = 0), no workgroup barriers; a strip stops
+// staging as soon as ITS pixels are saturated instead of waiting for the whole tile.
+template <int NP>
+__global__ void __launch_bounds__(64) render_fwd_strip_kernel(RenderArgs a) {
+    constexpr int PPL = 2 * NP;
+    constexpr int PARTS = 4 / PPL;
+    const int unit = unit_of_block(blockIdx.x, a.gx * a.gy * PARTS);
+    if (unit < 0) return;
+    const int tile = unit / PARTS, part = unit - tile * PARTS;
+    __shared__ float4 sA[64], sB[64], sC[64];
+    const int lane = threadIdx.x;
+    const int x = (tile % a.gx) * TILE + (lane & 15);
+    const int y0 = (tile / a.gx) * TILE + part * (4 * PPL) + (lane >> 4);
+    const float pxf = (float)x;
+    const uint2 range = a.ranges[tile];
+    const int todo = (int)(range.y - range.x);
+    v2f py[NP], T[NP], C0[NP], C1[NP], C2[NP], Dp[NP];
+    bool done[PPL];
+    uint32_t last[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const int y = y0 + 4 * i;
+        py[i >> 1][i & 1] = (float)y;
+        done[i] = !(x < a.W && y < a.H);
+        last[i] = 0;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) { T[p] = splat2(1.0f); C0[p] = C1[p] = C2[p] = Dp[p] = splat2(0.f); }
+    const int rounds = (todo + 63) >> 6;
+    auto gid_of = [&](int r) -> uint32_t {
+        const int e = r * 64 + lane;
+        return a.pair_gid[range.x + (e < todo ? e : (todo > 0 ? todo - 1 : 0))];
+    };
+    uint32_t g_cur = 0, g_nxt = 0;
+    float4 rA = make_float4(0.f, 0.f, 0.f, 0.f), rB = rA, rC = rA;
+    if (rounds > 0) { g_cur = gid_of(0); rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
+    if (rounds > 1) g_nxt = gid_of(1);
+    for (int r = 0; r < rounds; r++) {
+        bool all_done = true;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) all_done = all_done && done[i];
+        if (__all(all_done)) break;
+        __syncthreads();
+        sA[lane] = rA; sB[lane] = rB; sC[lane] = rC;
+        __syncthreads();
+        if (r + 1 < rounds) { g_cur = g_nxt; rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
+        if (r + 2 < rounds) g_nxt = gid_of(r + 2);
+        const int rem = todo - r * 64;
+        const int lim = rem < 64 ? rem : 64;
+        for (int j = 0; j < lim; j++) {
+            const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
+            const float4 A = sA[j];
+            const float4 B = sB[j];
+            const float4 Cc = sC[j];
+            const float dx = A.x - pxf;
+            const float u1 = blend_power_xx(A.z, dx);
+            const float cx = blend_power_xy(A.w, dx);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const v2f dy = splat2(A.y) - py[p];
+                const v2f power = blend_power2(u1, cx, B.x, dy);
+                v2f alpha;
+                alpha[0] = fminf(FDGS_ALPHA_MAX, B.y * __expf(fminf(power[0], 0.0f)));
+                alpha[1] = fminf(FDGS_ALPHA_MAX, B.y * __expf(fminf(power[1], 0.0f)));
+                const v2f test_T = T[p] * (splat2(1.0f) - alpha);
+                v2f w;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int i = 2 * p + c;
+                    const bool cand = !done[i] && !(power[c] > 0.0f) && !(alpha[c] < FDGS_ALPHA_MIN);
+                    const bool stop = cand && (test_T[c] < FDGS_T_STOP);
+                    const bool blend = cand && !stop;
+                    done[i] = done[i] || stop;
+                    w[c] = blend ? alpha[c] * T[p][c] : 0.f;
+                    T[p][c] = blend ? test_T[c] : T[p][c];
+                    last[i] = blend ? contributor : last[i];
+                }
+                C0[p] = fma2(splat2(Cc.x), w, C0[p]); C1[p] = fma2(splat2(Cc.y), w, C1[p]); C2[p] = fma2(splat2(Cc.z), w, C2[p]);
+                Dp[p] = fma2(splat2(B.z), w, Dp[p]);
+            }
+        }
+    }
+    const size_t hw = (size_t)a.H * a.W;
+#pragma unroll
+    for (int i = 0; i < PPL; i++) {
+        const int y = y0 + 4 * i, p = i >> 1, c = i & 1;
+        if (x < a.W && y < a.H) {
+            const size_t pix = (size_t)y * a.W + x;
+            a.final_T[pix] = T[p][c]; a.n_contrib[pix] = last[i];
+            a.out_color[pix] = C0[p][c] + T[p][c] * a.bg[0];
+            a.out_color[hw + pix] = C1[p][c] + T[p][c] * a.bg[1];
+            a.out_color[2 * hw + pix] = C2[p][c] + T[p][c] * a.bg[2];
+            a.out_depth[pix] = Dp[p][c];
+        }
+    }
+}
+
 int validate_raster_params(const fdgs_raster_params* p);
 
 }  // namespace fdgs
@@ -292,7 +587,18 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
     a.out_color = out_color; a.out_depth = out_depth;
     const int ntiles = il.gx * il.gy;
-    { FDGS_TIMED("render_fwd", stream); hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a); }
+    {
+        FDGS_TIMED("render_fwd", stream);
+        const int ppl = tunable("FDGS_RFWD_PPL", 4);      // pixels per lane of the strip form; 0 = the 256-thread form
+        if (ppl == 2 || ppl == 4) {
+            const int units = ntiles * (4 / ppl);
+            const dim3 sgrid(8 * ((units + 7) / 8));
+            if (ppl == 2) hipLaunchKernelGGL(render_fwd_strip_kernel<1>, sgrid, dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(render_fwd_strip_kernel<2>, sgrid, dim3(64), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+        }
+    }
     FDGS_LAUNCH_CHECK("render_fwd", p->debug, stream);
     return FDGS_OK;
 }
@@ -336,7 +642,16 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
             // entries staged per round: 128 keeps six workgroups per CU (25 KB of LDS each), 256 halves the barriers at three per CU
             const int round = tunable("FDGS_RBWD_ROUND", 128);
             const dim3 grid(8 * ((ntiles + 7) / 8));
-            if (g->dL_ddepth) {
+            // pixels per lane of the strip form (1 wave per workgroup); 0 = the 256-thread form
+            const int ppl = tunable("FDGS_RBWD_PPL", 4);
+            if (ppl == 2 || ppl == 4) {
+                const int units = ntiles * (4 / ppl);
+                const dim3 sgrid(8 * ((units + 7) / 8));
+#define FDGS_STRIP(D_, P_) hipLaunchKernelGGL((render_bwd_strip_kernel<D_, P_>), sgrid, dim3(64), 0, stream, a)
+                if (g->dL_ddepth) { if (ppl == 2) FDGS_STRIP(true, 1); else FDGS_STRIP(true, 2); }
+                else { if (ppl == 2) FDGS_STRIP(false, 1); else FDGS_STRIP(false, 2); }
+#undef FDGS_STRIP
+            } else if (g->dL_ddepth) {
                 if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<true, 256>), grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL((render_bwd_kernel<true, 128>), grid, dim3(256), 0, stream, a);
             } else {

@@ -444,6 +444,7 @@ def test_spatial_order_hint_selects_the_plane_gradient_kernel_not_the_result():
     """The order hint is measured from the positions (once per tensor object) and only chooses between two equivalent kernels."""
     fd = _fdgs()
     dev = torch.device("cuda:0")
+    fd.deformation.invalidate_caches()      # (earlier tests leave an answer for fresh [20000,3] tensors behind: the "streak" shortcut)
     g = synthetic.make_gaussians(20000, seed=3)
     x = g["xyz"].to(dev)
     assert fd.deformation.spatial_order_hint(x) is False
@@ -493,8 +494,11 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
         worst[k] = rel_l2(a.cpu().numpy(), b.cpu().numpy())
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     print("   skip vs no-skip worst rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in top))
+    numel = {k: (0 if b is None else b.numel()) for k, b in zip(names, res["0"][0])}
     for k, v in worst.items():
-        assert v < 2e-6, (k, v)
+        # a handful of values summed over all Gaussians in a different order (second-layer biases: k <= 48 numbers) carry the
+        # re-association noise un-averaged
+        assert v < (2e-5 if numel[k] <= 64 else 2e-6), (k, v)
     # rows without an upstream gradient receive exactly the identity-path zeros in both runs
     dead = (mask == 0).to(dev)
     for a in res["1"][0][:5]:
