@@ -15,10 +15,22 @@
 
 namespace fdgs {
 
-__device__ __forceinline__ int tile_of_block(int b, int ntiles) {
-    const int chunk = (ntiles + 7) >> 3;
-    const int tile = (b & 7) * chunk + (b >> 3);
-    return ((b >> 3) < chunk && tile < ntiles) ? tile : -1;
+// Workgroup b runs on XCD b % 8 (round-robin dispatch).  The tile rows are dealt to the XCDs in groups of `bh` rows: group G (rows
+// G*bh .. G*bh+bh-1) belongs to XCD G % 8, and an XCD walks its groups top to bottom.  Neighbouring tiles (which list the same Gaussians)
+// share an XCD's L2 inside a group, and every XCD owns rows from the whole height of the image: with ONE contiguous band per XCD (rounds
+// 1-2) the bands that only see the rim of the scene ran empty while the XCDs of the central bands carried the frame.
+// `parts` work units per tile (strip kernels: waves per tile), units of a tile adjacent.  Returns the unit index or -1.
+__device__ __forceinline__ int unit_of_block(int b, int gx, int gy, int parts, int bh) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int per_group = bh * gx * parts;
+    const int g = idx / per_group, rem = idx - g * per_group;
+    const int row = (g * 8 + xcd) * bh + rem / (gx * parts);
+    if (row >= gy) return -1;
+    return row * gx * parts + rem % (gx * parts);
+}
+__host__ __device__ __forceinline__ int unit_grid(int gx, int gy, int parts, int bh) {
+    const int groups = (gy + bh - 1) / bh;
+    return 8 * ((groups + 7) / 8) * bh * gx * parts;
 }
 
 // The exponent of a blended Gaussian, written so that EVERY kernel that evaluates it rounds it the same way (the forward decides
@@ -49,7 +61,7 @@ __device__ __forceinline__ v2f_ blend_power2(float u1, float cx, float cyy, v2f_
 }
 
 struct RenderArgs {
-    int W, H, gx, gy;
+    int W, H, gx, gy, bh;
     const uint2* ranges; const uint32_t* pair_gid;
     const float4 *recA, *recB, *recC;
     const float* bg;
@@ -58,7 +70,7 @@ struct RenderArgs {
 };
 
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
-    const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
+    const int tile = unit_of_block(blockIdx.x, a.gx, a.gy, 1, a.bh);
     if (tile < 0) return;
     __shared__ float4 sA[256], sB[256], sC[256];
     const int t = threadIdx.x;
@@ -138,8 +150,34 @@ __device__ __forceinline__ float row_allsum(float v) {
     return v;
 }
 
+// Sums of ten values over the 64 lanes of a wave as a reduce-scatter.  xor-1 and xor-2 butterflies inside the quads halve the values
+// per lane twice (lane bits 0,1 select which value a lane keeps); row_ror 4 / 8 add the four quads of a 16-lane row (they preserve
+// lane & 3); v_permlane16_swap / v_permlane32_swap on PAIRS of values add the four rows while halving once more.  On return
+//   lanes  0..15 hold sum(a[lane & 3]), lanes 16..31 sum(a[4 + (lane & 3)]), lanes 32..63 sum(a[8 + (lane & 1)]).
+template <bool TEN>
+__device__ __forceinline__ float wave_reduce_scatter10(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
+                                                       float a8, float a9, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // (the DPP moves stay unconditional: a select between two DPP results is compiled into divergent branches)
+    auto rs1 = [&](float lo, float hi) { const float keep = b0 ? hi : lo, send = b0 ? lo : hi; return keep + dpp_f<0xB1>(send); };   // lane ^ 1
+    auto rs2 = [&](float lo, float hi) { const float keep = b1 ? hi : lo, send = b1 ? lo : hi; return keep + dpp_f<0x4E>(send); };   // lane ^ 2
+    const float c0 = rs1(a0, a1), c1 = rs1(a2, a3), c2 = rs1(a4, a5), c3 = rs1(a6, a7);
+    const float c4 = TEN ? rs1(a8, a9) : a8 + dpp_f<0xB1>(a8);
+    float d0 = rs2(c0, c1), d1 = rs2(c2, c3), d2 = c4 + dpp_f<0x4E>(c4);
+    d0 += dpp_f<0x124>(d0); d1 += dpp_f<0x124>(d1); d2 += dpp_f<0x124>(d2);     // row_ror:4
+    d0 += dpp_f<0x128>(d0); d1 += dpp_f<0x128>(d1); d2 += dpp_f<0x128>(d2);     // row_ror:8
+    // rows: swap16(x, y) leaves x' = [x.r0, y.r0, x.r2, y.r2], y' = [x.r1, y.r1, x.r3, y.r3]
+    auto q01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0), __float_as_uint(d1), false, false);
+    const float e01 = __uint_as_float(q01[0]) + __uint_as_float(q01[1]);      // rows 0,2: d0 over a row pair; rows 1,3: d1
+    auto q2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d2), __float_as_uint(d2), false, false);
+    const float e2 = __uint_as_float(q2[0]) + __uint_as_float(q2[1]);
+    // swap32(x, y) leaves x' = [x.lo, y.lo], y' = [x.hi, y.hi]
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(e01), __float_as_uint(e2), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);                      // lower half: e01 totals, upper half: e2 totals
+}
+
 struct RenderBwdArgs {
-    int W, H, gx, gy;
+    int W, H, gx, gy, bh;
     const uint2* ranges; const uint32_t* pair_gid;
     const float4 *recA, *recB, *recC;
     const float* bg;
@@ -159,7 +197,7 @@ struct RenderBwdArgs {
 // profiles/r01_lds_atomic_microbench.txt, and rocprofv3 showed the waves waiting 39 % of their cycles.)
 template <bool DEPTH, int ROUND>
 __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
-    const int tile = tile_of_block(blockIdx.x, a.gx * a.gy);
+    const int tile = unit_of_block(blockIdx.x, a.gx, a.gy, 1, a.bh);
     if (tile < 0) return;
     constexpr int NV = DEPTH ? 10 : 9;
     __shared__ float4 sA[ROUND], sB[ROUND], sC[ROUND];
@@ -307,12 +345,6 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
 //     entry later);
 //   * a wave is its own workgroup: it stages its own 64 entries per round (records prefetched one round ahead, list ids two), never
 //     waits for another wave, and sends its sums straight to the gradient line (lanes 0..NV-1, one atomic instruction per entry).
-__device__ __forceinline__ int unit_of_block(int b, int nunits) {
-    const int chunk = (nunits + 7) >> 3;
-    const int u = (b & 7) * chunk + (b >> 3);
-    return ((b >> 3) < chunk && u < nunits) ? u : -1;
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
@@ -322,8 +354,7 @@ template <bool DEPTH, int NP>
 __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
     constexpr int PPL = 2 * NP;
     constexpr int PARTS = 4 / PPL;
-    constexpr int NV = DEPTH ? 10 : 9;
-    const int unit = unit_of_block(blockIdx.x, a.gx * a.gy * PARTS);
+    const int unit = unit_of_block(blockIdx.x, a.gx, a.gy, PARTS, a.bh);
     if (unit < 0) return;
     const int tile = unit / PARTS, part = unit - tile * PARTS;
     __shared__ float4 sA[64], sB[64], sC[64];
@@ -333,6 +364,9 @@ __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
     const int y0 = (tile / a.gx) * TILE + part * (4 * PPL) + (lane >> 4);
     const float pxf = (float)x;
     const size_t hw = (size_t)a.H * a.W;
+    // which of the per-Gaussian sums this lane holds after wave_reduce_scatter10, and whether it is the lane that sends it
+    const int slot = lane < 16 ? (lane & 3) : lane < 32 ? 4 + (lane & 3) : 8 + (lane & 1);
+    const bool slot_on = (lane & 15) < 4 && (lane < 32 || (lane < 48 && (lane & 15) < (DEPTH ? 2 : 1)));
     const uint2 range = a.ranges[tile];
     v2f py[NP], T[NP], tfb[NP], dp0[NP], dp1[NP], dp2[NP], ddep[NP], acc0[NP], acc1[NP], acc2[NP], accd[NP];
     uint32_t lastc[PPL];
@@ -442,25 +476,10 @@ __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
             float g_cxx = -0.5f * ux * dx, g_cxy = -0.5f * u1 * dx, g_cyy = -0.5f * u2;
             float g_op = V0[0] + V0[1];
             float g_c0 = gc0[0] + gc0[1], g_c1 = gc1[0] + gc1[1], g_c2 = gc2[0] + gc2[1], g_d = gd[0] + gd[1];
-            g_mx = row_allsum(g_mx); g_my = row_allsum(g_my);
-            g_cxx = row_allsum(g_cxx); g_cxy = row_allsum(g_cxy); g_cyy = row_allsum(g_cyy);
-            g_op = row_allsum(g_op);
-            g_c0 = row_allsum(g_c0); g_c1 = row_allsum(g_c1); g_c2 = row_allsum(g_c2);
-            if (DEPTH) g_d = row_allsum(g_d);
-            const int sub = lane & 15;
-            float v = g_mx;
-            v = sub == 1 ? g_my : v; v = sub == 2 ? g_cxx : v; v = sub == 3 ? g_cxy : v; v = sub == 4 ? g_cyy : v;
-            v = sub == 5 ? g_op : v; v = sub == 6 ? g_c0 : v; v = sub == 7 ? g_c1 : v; v = sub == 8 ? g_c2 : v;
-            if (DEPTH) v = sub == 9 ? g_d : v;
-            {
-                auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
-            }
-            {
-                auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-                v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
-            }
-            if (lane < NV && v != 0.f) atomicAdd(&a.gacc[(size_t)sGid[j] * 16 + lane], v);
+            // nine (ten) sums over the wave's 64 lanes as a reduce-scatter: each butterfly step halves the number of values a lane
+            // carries (36 instructions instead of 50 for nine all-reduces + select); lane `slot_lane` ends with value `slot`
+            const float v = wave_reduce_scatter10<DEPTH>(g_mx, g_my, g_cxx, g_cxy, g_cyy, g_op, g_c0, g_c1, g_c2, g_d, lane);
+            if (slot_on && v != 0.f) atomicAdd(&a.gacc[(size_t)sGid[j] * 16 + slot], v);
         }
     }
 }
@@ -472,7 +491,7 @@ template <int NP>
 __global__ void __launch_bounds__(64) render_fwd_strip_kernel(RenderArgs a) {
     constexpr int PPL = 2 * NP;
     constexpr int PARTS = 4 / PPL;
-    const int unit = unit_of_block(blockIdx.x, a.gx * a.gy * PARTS);
+    const int unit = unit_of_block(blockIdx.x, a.gx, a.gy, PARTS, a.bh);
     if (unit < 0) return;
     const int tile = unit / PARTS, part = unit - tile * PARTS;
     __shared__ float4 sA[64], sB[64], sC[64];
@@ -565,6 +584,12 @@ __global__ void __launch_bounds__(64) render_fwd_strip_kernel(RenderArgs a) {
 
 int validate_raster_params(const fdgs_raster_params* p);
 
+// tile rows per XCD group (unit_of_block): FDGS_XCD_ROWS, default 2; 0 = one contiguous band per XCD (the round-1/2 mapping)
+static int tile_rows_per_xcd_group(int gy) {
+    const int bh = tunable("FDGS_XCD_ROWS", 2);
+    return bh > 0 ? bh : (gy + 7) / 8;
+}
+
 }  // namespace fdgs
 
 int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, const void* geom, const fdgs_raster_grads* g);
@@ -581,22 +606,20 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     BinLayout bl = bin_layout(R);
     ImgLayout il = img_layout(p->W, p->H);
     RenderArgs a{};
-    a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy;
+    a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy; a.bh = tile_rows_per_xcd_group(il.gy);
     a.ranges = at<uint2>(img, il.ranges); a.pair_gid = binning ? at<uint32_t>(binning, bl.gid0) : nullptr;
     a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
     a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
     a.out_color = out_color; a.out_depth = out_depth;
-    const int ntiles = il.gx * il.gy;
     {
         FDGS_TIMED("render_fwd", stream);
-        const int ppl = tunable("FDGS_RFWD_PPL", 4);      // pixels per lane of the strip form; 0 = the 256-thread form
+        const int ppl = tunable("FDGS_RFWD_PPL", 0);      // pixels per lane of the strip form; 0 = the 256-thread form
         if (ppl == 2 || ppl == 4) {
-            const int units = ntiles * (4 / ppl);
-            const dim3 sgrid(8 * ((units + 7) / 8));
+            const dim3 sgrid(unit_grid(a.gx, a.gy, 4 / ppl, a.bh));
             if (ppl == 2) hipLaunchKernelGGL(render_fwd_strip_kernel<1>, sgrid, dim3(64), 0, stream, a);
             else hipLaunchKernelGGL(render_fwd_strip_kernel<2>, sgrid, dim3(64), 0, stream, a);
         } else {
-            hipLaunchKernelGGL(render_fwd_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(render_fwd_kernel, dim3(unit_grid(a.gx, a.gy, 1, a.bh)), dim3(256), 0, stream, a);
         }
     }
     FDGS_LAUNCH_CHECK("render_fwd", p->debug, stream);
@@ -630,26 +653,25 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     ImgLayout il = img_layout(p->W, p->H);
     if (R > 0) {
         RenderBwdArgs a{};
-        a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy;
+        a.W = p->W; a.H = p->H; a.gx = il.gx; a.gy = il.gy; a.bh = tile_rows_per_xcd_group(il.gy);
         a.ranges = at<uint2>(img, il.ranges); a.pair_gid = at<uint32_t>(binning, bl.gid0);
         a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
         a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
         a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
         a.gacc = g->scratch_acc;
-        const int ntiles = il.gx * il.gy;
         {
             FDGS_TIMED("render_bwd", stream);
             // entries staged per round: 128 keeps six workgroups per CU (25 KB of LDS each), 256 halves the barriers at three per CU
             const int round = tunable("FDGS_RBWD_ROUND", 128);
-            const dim3 grid(8 * ((ntiles + 7) / 8));
+            const dim3 grid(unit_grid(a.gx, a.gy, 1, a.bh));
             // pixels per lane of the strip form (1 wave per workgroup); 0 = the 256-thread form
             const int ppl = tunable("FDGS_RBWD_PPL", 4);
             if (ppl == 2 || ppl == 4) {
-                const int units = ntiles * (4 / ppl);
-                const dim3 sgrid(8 * ((units + 7) / 8));
+                const dim3 sgrid(unit_grid(a.gx, a.gy, 4 / ppl, a.bh));
 #define FDGS_STRIP(D_, P_) hipLaunchKernelGGL((render_bwd_strip_kernel<D_, P_>), sgrid, dim3(64), 0, stream, a)
                 if (g->dL_ddepth) { if (ppl == 2) FDGS_STRIP(true, 1); else FDGS_STRIP(true, 2); }
-                else { if (ppl == 2) FDGS_STRIP(false, 1); else FDGS_STRIP(false, 2); }
+                else if (ppl == 2) FDGS_STRIP(false, 1);
+                else FDGS_STRIP(false, 2);
 #undef FDGS_STRIP
             } else if (g->dL_ddepth) {
                 if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<true, 256>), grid, dim3(256), 0, stream, a);

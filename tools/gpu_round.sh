@@ -43,7 +43,7 @@ WL0=cfg4_dynerf_300k_1352x1014
 if [ -z "$SKIP_PROF" ]; then prof_one $WL0 ""; fi
 if [ -n "$PMC" ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq -o pmc --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq -o pmc --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   cd $R
   python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq gpurun_out/${TAG}_pmc_sq.txt > /dev/null
   head -8 gpurun_out/${TAG}_pmc_sq.txt | cut -c1-230
