@@ -152,7 +152,7 @@ def max_over_ranks(value, device):
 
 
 # ---- data-parallel train step: every rank renders its own views, gradients are summed ----
-def allreduce_gradients(params, bucket_bytes=512 << 20, average=False):
+def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zero_copy=True):
     """Sum (or average) `.grad` of `params` over the ranks, in place.
 
     The reference sums the losses of the `batch_size` views of one step before one backward (train.py:180-219), so the
@@ -171,9 +171,47 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False):
     if not params:
         return 0
     dev0 = next((p.grad.device for p in params if p.grad is not None), params[0].device)
-    has = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev0)
+    # Layout signature: the fused render path hands every gradient back as a VIEW OF ONE ARENA (deformation.backward_prepare), so the
+    # arena itself can be the all-reduce buffer -- no torch.cat into a bucket, no copy back.  That is only legal when every rank has
+    # the same view structure (same parameter -> (storage ordinal, element offset, numel)); a rank whose gradient is None, or that came
+    # through another code path, has a different signature, MIN != MAX below, and every rank takes the packing path together.
+    stor, layout = {}, []
+    for p_ in params:
+        g = p_.grad
+        # (dense = numel consecutive elements from storage_offset: row-major, or channels-last like the HexPlane gradients)
+        if g is None or not (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))):
+            layout.append(None)
+            continue
+        sid = stor.setdefault(g.untyped_storage().data_ptr(), len(stor))
+        layout.append((sid, g.storage_offset(), g.numel(), str(g.dtype)))
+    sig = hash(tuple(layout)) & 0x3FFFFFFFFFFFFFF
+    s_lo, s_hi = int(sig & 0x3FFFFFFF), int((sig >> 30) & 0x3FFFFFF)
+    has = torch.tensor([0 if p_.grad is None else 1 for p_ in params] + [s_lo, s_hi, -s_lo, -s_hi], dtype=torch.int32, device=dev0)
     dist.all_reduce(has, op=dist.ReduceOp.MAX)
     has = has.tolist()
+    same_layout = all(l is not None for l in layout) and has[-4] == -has[-2] and has[-3] == -has[-1]
+    has = has[:-4]
+    if same_layout and arena_zero_copy:
+        # one flat view per storage, spanning its first to its last gradient element (alignment gaps inside the span are reduced
+        # along with the rest: nobody reads them), cut into bucket-sized pieces without copying
+        calls = 0
+        spans = {}
+        for p_, l in zip(params, layout):
+            lo, hi = spans.get(l[0], (l[1], l[1] + l[2]))
+            spans[l[0]] = (min(lo, l[1]), max(hi, l[1] + l[2]))
+            spans.setdefault(("t", l[0]), p_.grad)
+        for sid in sorted(k for k in spans if not isinstance(k, tuple)):
+            lo, hi = spans[sid]
+            g0 = spans[("t", sid)]
+            flat = torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,))
+            step = max(1, bucket_bytes // flat.element_size())
+            for a0 in range(0, hi - lo, step):
+                piece = flat[a0:a0 + step]
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                if average:
+                    piece.div_(world)
+                calls += 1
+        return calls
     groups = {}
     for p, h in zip(params, has):
         if not h:

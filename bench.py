@@ -562,11 +562,14 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
         if fi == 0:   # the oracle's image, depth and every gradient of this frame: the checker of parity_vs_oracle()
             names = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
             ref = dict(color=o.color.copy(), depth=o.depth.copy(), dc=dc, means2D=g["means2D"].copy(), radii=o.radii.copy(),
-                       grads={k: (None if v is None else v.numpy()) for k, v in zip(names, gref)})
+                       grads={k: (None if v is None else v.numpy()) for k, v in zip(names, gref)}, gouts=[x.clone() for x in gouts])
         o.close()
         for k_, v_ in zip(stage, (tb - ta, tc - tb, td - tc, te - td)):
             stage[k_] += v_
     dt = time.perf_counter() - t0
+    # outside the timed sample: the float64 re-evaluation of the deformation backward of frame 0 (live rows only) -- the gradient
+    # reference that is not itself at the mercy of one ReLU kink (oracle/deform_oracle.py: backward_float64)
+    ref["grads64"] = DO.backward_float64(sd, flags, leaves, cam.time, ref.pop("gouts"))
     return ({"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s wall on {threads} threads of {cores} host cores; "
                       "deformation = oracle pinned to the reference modules (torch CPU), rasterizer = our C restatement (OpenMP)",
@@ -598,11 +601,13 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
               "f_rest": ["_features_rest"],
               "planes": [k for k in ref["grads"] if "grids" in k and ref["grads"][k] is not None],
               "mlp": [k for k in ref["grads"] if k.startswith("_deformation.") and "grids" not in k and ref["grads"][k] is not None]}
-    grad_rel = {}
+    grad_rel, grad_rel64 = {}, {}
     for gname, keys in groups.items():
         a = np.concatenate([named[k].grad.detach().cpu().numpy().ravel() for k in keys])
         b = np.concatenate([ref["grads"][k].ravel() for k in keys])
         grad_rel[gname] = rel(a, b)
+        if ref.get("grads64"):
+            grad_rel64[gname] = rel(a, np.concatenate([ref["grads64"][k].ravel() for k in keys]))
     worst_tensor = max(((k, rel(named[k].grad.detach().cpu().numpy(), v)) for k, v in ref["grads"].items()
                         if v is not None and float(np.abs(v).max()) > 0), key=lambda kv: kv[1])
     radii = res["radii"].cpu().numpy()
@@ -615,6 +620,10 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
             "depth_mean_abs": float(np.abs(dp - ref["depth"]).mean()),
             "radii_mismatch_frac": float((radii != ref["radii"]).mean()),
             "grad_rel_l2": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},
+            # the same HIP gradients against a float64 evaluation of the oracle's deformation backward (same float32 upstream gradients):
+            # the float32 oracle has the same ReLU / border kinks as any float32 implementation, the per-Gaussian gradient magnitudes are
+            # heavy-tailed, and a single Gaussian rounding to the other side of a kink moves a group's rel-L2 by ~1e-3
+            "grad_rel_l2_vs_float64_oracle": {k: float(f"{v:.3e}") for k, v in grad_rel64.items()},
             "viewspace_rel_l2": float(f"{rel(res['viewspace_points'].grad.cpu().numpy(), ref['means2D']):.3e}"),
             "worst_single_tensor": {"name": worst_tensor[0], "rel_l2": float(f"{worst_tensor[1]:.3e}")},
             "tolerance": {"image_psnr_dB": ">= 80", "grad_rel_l2": "<= 1e-3 (north_star)"}}

@@ -119,6 +119,44 @@ def discontinuity_margin(sd, flags, xyz, t):
     return margin
 
 
+def backward_float64(sd, flags, leaves, t_value, gouts):
+    """Gradients of deform_forward(activate=True) w.r.t. every parameter, evaluated in FLOAT64 for given (float32) upstream gradients
+    `gouts` = [d/d means3D, d/d scales, d/d rotations, d/d opacity, d/d shs] -- the reference for gradient-parity checks where the
+    float32 autograd of this same oracle is not accurate enough to be the judge: the field has kinks (ReLU, border clamp), the
+    per-Gaussian gradient magnitudes of a rendered frame are heavy-tailed, and ONE Gaussian whose pre-activation rounds to the
+    other side of zero in float32 moves the rel-L2 of a whole tensor by ~1e-3 (measured: 99.99 % of the squared float32-vs-float64
+    difference of the 2 M-Gaussian frame sits in ten rows, tools/oracle_f32_vs_f64.py).  Rows whose upstream gradients are all zero
+    (culled / occluded Gaussians) contribute exactly zero to every sum and are left out of the evaluation.
+    `leaves`: dict of the six Gaussian tensors (_xyz, _scaling, _rotation, _opacity, _features_dc, _features_rest).
+    Returns {name: float64 numpy array or None} with the state-dict names prefixed "_deformation."."""
+    dt = torch.float64
+    n = leaves["_xyz"].shape[0]
+    live = torch.zeros(n, dtype=torch.bool)
+    for g in gouts:
+        live |= (g.reshape(n, -1) != 0).any(dim=1)
+    idx = torch.nonzero(live).squeeze(1)
+    sd64 = {k: (v.detach().to(dt).requires_grad_(bool(v.requires_grad)) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    sub = {k: v.detach()[idx].to(dt).requires_grad_(True) for k, v in leaves.items()}
+    shs = torch.cat([sub["_features_dc"], sub["_features_rest"]], 1)
+    outs = deform_forward(sd64, flags, sub["_xyz"], sub["_scaling"], sub["_rotation"], sub["_opacity"], shs,
+                          torch.full((idx.numel(), 1), float(t_value), dtype=dt), activate=True)
+    g64 = [g.detach()[idx].to(dt).reshape(o.shape) for g, o in zip(gouts, outs)]
+    wanted = list(sub.values()) + [v for v in sd64.values() if v.dtype.is_floating_point and v.requires_grad]
+    names = list(sub.keys()) + ["_deformation." + k for k, v in sd64.items() if v.dtype.is_floating_point and v.requires_grad]
+    grads = torch.autograd.grad(list(outs), wanted, grad_outputs=g64, allow_unused=True)
+    out = {}
+    for k, g in zip(names, grads):
+        if g is None:
+            out[k] = None
+        elif k in sub:
+            full = torch.zeros((n,) + tuple(g.shape[1:]), dtype=dt)
+            full[idx] = g
+            out[k] = full.numpy()
+        else:
+            out[k] = g.numpy()
+    return out
+
+
 def import_reference_deform_network():
     """import the reference's own deform_network on CPU (only where /root/reference exists)."""
     import sys

@@ -35,9 +35,9 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
     forward -> L1-loss image gradient against a seeded random target -> C analytic backward -> torch-CPU autograd through the
     deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, {parameter name: gradient or None}).
     `grad_dtype=torch.float64`: the autograd pass through the deformation is a float64 re-evaluation of the same oracle function fed
-    with the same (float32-chain) upstream gradients.  At 2 M Gaussians the float32 autograd of the oracle is itself 1.1e-3 (planes) /
-    9e-4 (xyz) / 3e-4 (MLP) away from its own float64 evaluation (tools/oracle_f32_vs_f64.py) -- more than the tolerance it is meant
-    to check."""
+    with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64).  On the 2 M-Gaussian frame the float32
+    autograd of the oracle is itself 1.1e-3 (planes) / 9e-4 (xyz) / 3e-4 (MLP) away from its own float64 evaluation
+    (tools/oracle_f32_vs_f64.py: one Gaussian's ReLU kink) -- more than the tolerance it is meant to check."""
     from oracle import deform_oracle as DO
     from oracle.raster_oracle import RasterOracle
     n = pc._xyz.shape[0]
@@ -67,16 +67,11 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
     gouts = [torch.tensor(go["means3D"]), torch.tensor(go["scales"]), torch.tensor(go["rotations"]),
              torch.tensor(go["opacities"]).reshape(op.shape), torch.tensor(go["shs"]).reshape(sh.shape)]
     if grad_dtype != torch.float32 and stage == "fine":
-        dt = grad_dtype
-        sd = {k: (v.detach().clone().to(dt).requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v) for k, v in sd.items()}
-        leaves = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in leaves.items()}
-        shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
-        outs = list(DO.deform_forward(sd, pc._deformation.args, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"],
-                                      shs, torch.full((n, 1), cam.time, dtype=dt), activate=True))
-        gouts = [g.to(dt) for g in gouts]
-    wanted = list(leaves.values()) + ([v for v in sd.values() if v.requires_grad] if stage == "fine" else [])
-    wnames = list(leaves.keys()) + (["_deformation." + k for k, v in sd.items() if v.requires_grad] if stage == "fine" else [])
-    g_ref = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
-    grads = {k: (None if g is None else g.double().numpy() if grad_dtype != torch.float32 else g.numpy()) for k, g in zip(wnames, g_ref)}
+        grads = DO.backward_float64(sd, pc._deformation.args, leaves, cam.time, gouts)
+    else:
+        wanted = list(leaves.values()) + ([v for v in sd.values() if v.requires_grad] if stage == "fine" else [])
+        wnames = list(leaves.keys()) + (["_deformation." + k for k, v in sd.items() if v.requires_grad] if stage == "fine" else [])
+        g_ref = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
+        grads = {k: (None if g is None else g.numpy()) for k, g in zip(wnames, g_ref)}
     grads["__means2D"] = go["means2D"]
     return o, dc, dd, grads

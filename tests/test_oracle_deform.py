@@ -85,3 +85,39 @@ def test_border_and_flip_semantics():
     sd["deformation_net.grid.grids.0.0"] = ramp  # plane (x,y): width indexes x
     f = DO.hexplane_features(sd, torch.tensor([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0], [5.0, 0.0, 0.0]]), torch.zeros(3, 1), 1)
     assert torch.allclose(f[:, 0], torch.tensor([0.0, 6.0, 0.0]))
+
+
+def test_float64_backward_of_live_rows_matches_the_float32_autograd():
+    """oracle.deform_oracle.backward_float64 (the gradient reference of the full-size parity checks) = the float32 autograd of the same
+    oracle up to float32 rounding, with rows whose upstream gradients are all zero left out of the evaluation."""
+    import importlib
+    import numpy as np
+    syn = importlib.import_module("4dgaussians_amd.synthetic")
+    pc = syn.SynthModel(600, "dynerf_default", seed=5)
+    n = 600
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in pc._deformation.state_dict().items()}
+    leaves = {k: getattr(pc, k).detach().clone().requires_grad_(True)
+              for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
+    shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
+    outs = DO.deform_forward(sd, pc._deformation.args, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
+                             torch.full((n, 1), 0.37), activate=True)
+    g = torch.Generator().manual_seed(9)
+    mask = (torch.rand(n, generator=g) < 0.3).float()                 # 70 % of the rows get no gradient at all
+    gouts = [torch.randn(o.shape, generator=g) * mask.reshape([-1] + [1] * (o.dim() - 1)) for o in outs]
+    wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
+    names = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
+    g32 = dict(zip(names, torch.autograd.grad(list(outs), wanted, grad_outputs=gouts, allow_unused=True)))
+    g64 = DO.backward_float64(sd, pc._deformation.args, leaves, 0.37, gouts)
+    assert set(g64) == set(g32)
+    for k, a in g32.items():
+        b = g64[k]
+        if a is None:
+            assert b is None or float(np.abs(b).max()) == 0.0, k
+            continue
+        a = a.double().numpy()
+        assert b.shape == a.shape, k
+        den = np.linalg.norm(b)
+        assert np.linalg.norm(a - b) <= 2e-5 * den + 1e-12, (k, np.linalg.norm(a - b) / max(den, 1e-30))
+    dead = mask == 0
+    assert float(np.abs(g64["_xyz"][dead.numpy()]).max()) == 0.0

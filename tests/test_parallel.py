@@ -112,6 +112,82 @@ def test_two_rank_gradient_and_densification_allreduce():
         assert torch.allclose(torch.tensor(r[7]), torch.full((4, 3), 3.0))
 
 
+def _arena_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    par.init_from_env(backend="gloo")
+    shapes = [(40, 3), (40, 4), (1, 8, 6, 5), (7,), (16, 16)]
+
+    def make(seed):
+        # gradients as the fused render path leaves them: views of ONE arena at 64-element aligned offsets, planes channels-last
+        g = torch.Generator().manual_seed(seed)
+        sizes = [(int(torch.Size(s_).numel()) + 63) // 64 * 64 for s_ in shapes]
+        arena = torch.full((sum(sizes),), float("nan"))            # (gaps stay garbage: nobody may read them)
+        params, off = [], 0
+        for s_, n_ in zip(shapes, sizes):
+            numel = int(torch.Size(s_).numel())
+            v = arena[off:off + numel]
+            if len(s_) == 4:
+                v = v.view(s_[0], s_[2], s_[3], s_[1]).permute(0, 3, 1, 2)     # logical [1,C,H,W], channels-last memory
+            else:
+                v = v.view(s_)
+            v.copy_(torch.randn(*s_, generator=g))
+            p_ = torch.nn.Parameter(torch.zeros(*s_))
+            if len(s_) == 4:
+                p_.data = p_.data.contiguous(memory_format=torch.channels_last)
+            p_.grad = v
+            params.append(p_)
+            off += n_
+        return arena, params
+
+    arena, params = make(100 + rank)
+    ptr0 = [p_.grad.data_ptr() for p_ in params]
+    calls = par.allreduce_gradients(params)
+    same_storage = [p_.grad.data_ptr() for p_ in params] == ptr0
+    got = [p_.grad.contiguous().clone() for p_ in params]
+    # same data through the packing path (zero-copy off) must agree
+    arena2, params2 = make(100 + rank)
+    calls2 = par.allreduce_gradients(params2, arena_zero_copy=False)
+    agree = all(torch.allclose(a.contiguous(), b.grad.contiguous()) for a, b in zip(got, params2))
+    # one rank lost a gradient: the signature differs, every rank falls back to packing together (no hang, right sums)
+    arena3, params3 = make(100 + rank)
+    if rank == 1:
+        params3[3].grad = None
+    calls3 = par.allreduce_gradients(params3)
+    q.put((rank, calls, same_storage, calls2, agree, calls3, [g_.tolist() for g_ in got], params3[3].grad.tolist(), params3[0].grad.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_runs_in_place_on_the_gradient_arena():
+    """When every rank holds its gradients as views of one arena with the same layout (what the fused render backward returns), the
+    arena is the all-reduce buffer: one collective, no packing copy, gradients stay where they are; a rank with a different layout
+    sends everybody down the packing path."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_arena_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shapes = [(40, 3), (40, 4), (1, 8, 6, 5), (7,), (16, 16)]
+    want = None
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        vals = [torch.randn(*s_, generator=g) for s_ in shapes]
+        want = vals if want is None else [a + b for a, b in zip(want, vals)]
+    g1 = torch.Generator().manual_seed(100)
+    first = [torch.randn(*s_, generator=g1) for s_ in shapes]
+    for r in res:
+        assert r[1] == 1 and r[2] is True and r[3] == 1 and r[4] is True and r[5] == 1
+        for got, w in zip(r[6], want):
+            assert torch.allclose(torch.tensor(got), w, atol=1e-6)
+        assert torch.allclose(torch.tensor(r[7]), first[3], atol=1e-6)       # only rank 0 had this one: sum = rank 0's values
+        assert torch.allclose(torch.tensor(r[8]), want[0], atol=1e-6)
+
+
 def test_single_process_is_a_noop():
     par = importlib.import_module("4dgaussians_amd.parallel")
     acc = torch.tensor([1.0, 2.0, 3.0])
