@@ -152,7 +152,10 @@ def run(args, make_step=None):
     bg = torch.zeros(3, device=dev)
     cams = [c.to(dev) for c in syn.orbit_cameras(W, H, n=160)]
     target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(6666)).to(dev)
-    acc = torch.zeros(3, device=dev)
+    # loss statistics: two buffers, the all-reduce of step i runs under step i + 1 (parallel.allreduce_loss_stats(async_op=True))
+    accs = [torch.zeros(3, device=dev), torch.zeros(3, device=dev)]
+    pending = [None, None]
+    acc = accs[0]
     dimg = torch.empty(3, H, W, device=dev)
     st = fdgs._lib.stream_ptr
     ptr = fdgs._lib.ptr
@@ -167,12 +170,16 @@ def run(args, make_step=None):
                 p_.grad = None
             res = fdgs.render(cam, model, pipe, bg, stage="fine")
             img = res["render"]
-            acc.zero_()
-            fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc)))
+            b_ = i & 1
+            acc_ = accs[b_]
+            if pending[b_] is not None:
+                pending[b_].wait()          # (the reduction issued two steps ago: long done; orders the buffer's reuse)
+            acc_.zero_()
+            fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc_)))
             img.backward(dimg)
-            par.allreduce_loss_stats(acc)   # the only cross-GPU exchange of the path
-            info["radii"], info["vsp"], info["vis"] = res["radii"], res["viewspace_points"], res["visibility_filter"]
-            return acc
+            pending[b_] = par.allreduce_loss_stats(acc_, async_op=True)   # the only cross-GPU exchange of the path, under the next step
+            info["radii"], info["vsp"], info["vis"], info["acc"] = res["radii"], res["viewspace_points"], res["visibility_filter"], acc_
+            return acc_
         return step
 
     step = make_render_step(pc)
@@ -195,7 +202,10 @@ def run(args, make_step=None):
     dt = sorted(regions)[len(regions) // 2]
     per_rank_ms = [x / args.steps * 1e3 for x in par.gather_floats(sorted(local_regions)[len(local_regions) // 2], dev)]
     per_rank_startup = par.gather_floats(startup_s, dev)
-    l1, psnr = par.loss_from_stats(acc.clone())
+    for w_ in pending:
+        if w_ is not None:
+            w_.wait()
+    l1, psnr = par.loss_from_stats(info.get("acc", acc).clone())
     fps = world * args.steps / dt
     ms_regions = [x / args.steps * 1e3 for x in regions]
 

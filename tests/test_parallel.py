@@ -33,7 +33,12 @@ def _worker(rank, world, port, q):
         frames.append(i)
         d = imgs[i] - tgts[i]
         acc = torch.tensor([d.abs().sum(), (d * d).sum(), float(d.numel())])
-        par.allreduce_loss_stats(acc)
+        if step == 0:
+            par.allreduce_loss_stats(acc)
+        else:                                   # the overlapped form bench.py uses: a handle, waited for before the buffer is read
+            h = par.allreduce_loss_stats(acc, async_op=True)
+            assert h is not None
+            h.wait()
         total += acc
     par.barrier()
     t = par.max_over_ranks(0.5 + rank, dev)
@@ -192,6 +197,7 @@ def test_single_process_is_a_noop():
     par = importlib.import_module("4dgaussians_amd.parallel")
     acc = torch.tensor([1.0, 2.0, 3.0])
     assert torch.equal(par.allreduce_loss_stats(acc.clone()), acc)
+    assert par.allreduce_loss_stats(acc.clone(), async_op=True) is None
     assert par.frames_for_rank(160, 5, 0, 1) == 5
     p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.ones(3)
     assert par.allreduce_gradients([p]) == 0 and torch.equal(p.grad, torch.ones(3))
