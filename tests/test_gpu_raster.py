@@ -324,3 +324,39 @@ def test_tile_culling_is_exact(case, monkeypatch):
     assert rel_l2(b[4].cpu().numpy(), a[4].cpu().numpy()) < 1e-5
     assert b[5] <= a[5] and (b[5] < a[5] or case.get("scale_boost", 1.0) >= 10.0)
     print(f"[{case}] pairs {a[5]} -> {b[5]} ({100.0 * b[5] / a[5]:.1f} %)")
+
+
+@pytest.mark.parametrize("with_depth", [False, True])
+def test_blending_kernel_forms_agree(with_depth, monkeypatch):
+    """The blending kernels exist in several shapes selected by development knobs -- backward: one wave per tile with four pixels per
+    lane (default), two waves with two pixels per lane (FDGS_RBWD_PPL=2), the 256-thread form of rounds 1-2 (FDGS_RBWD_PPL=0);
+    forward: the 256-thread form (default) and the strip forms (FDGS_RFWD_PPL=2/4).  All of them must produce the same image,
+    the same per-pixel bookkeeping and the same gradients up to the association of the sums."""
+    dev = torch.device("cuda:0")
+    sc = raster_scene(6000, 232, 152, seed=11, scale_boost=2.0)
+    R = _mod().rasterizer
+    rng = np.random.default_rng(3)
+    wc = torch.tensor(rng.standard_normal((3, 152, 232)).astype(np.float32), device=dev)
+    wd = torch.tensor(rng.standard_normal((1, 152, 232)).astype(np.float32), device=dev)
+    outs = {}
+    for name, env in (("default", {}), ("bwd2", {"FDGS_RBWD_PPL": "2"}), ("bwd0", {"FDGS_RBWD_PPL": "0"}), ("fwd2", {"FDGS_RFWD_PPL": "2"}),
+                      ("fwd4", {"FDGS_RFWD_PPL": "4"}), ("bands", {"FDGS_XCD_ROWS": "0"})):
+        for k in ("FDGS_RBWD_PPL", "FDGS_RFWD_PPL", "FDGS_XCD_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        means2D = torch.zeros_like(t["means3D"], requires_grad=True)
+        rast = R.GaussianRasterizer(_settings(sc, dev))
+        color, radii, depth = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                                   scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        loss = (color * wc).sum() + ((depth * wd).sum() if with_depth else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[name] = (color.detach().cpu().numpy(), depth.detach().cpu().numpy(),
+                      {k: v.grad.cpu().numpy() for k, v in t.items()} | {"means2D": means2D.grad.cpu().numpy()})
+    c0, d0, g0 = outs["default"]
+    for name, (c, d, g) in outs.items():
+        assert np.abs(c - c0).max() <= 1e-6 and np.abs(d - d0).max() <= 1e-5, name       # (forward forms: same arithmetic, fma order only)
+        for k in g0:
+            assert rel_l2(g[k], g0[k]) < 5e-6, (name, k, rel_l2(g[k], g0[k]))
