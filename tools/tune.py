@@ -31,10 +31,16 @@ SWEEPS = [
     ("pg_wgs=2048", {"FDGS_PG_WGS": "2048"}),
     ("d2_wgs=128", {"FDGS_D2_WGS": "128"}),
     ("d2_wgs=512", {"FDGS_D2_WGS": "512"}),
+    ("wgrad_wgs=64", {"FDGS_WGRAD_WGS": "64"}),
+    ("wgrad_wgs=96", {"FDGS_WGRAD_WGS": "96"}),
     ("wgrad_wgs=128", {"FDGS_WGRAD_WGS": "128"}),
+    ("wgrad_wgs=192", {"FDGS_WGRAD_WGS": "192"}),
     ("wgrad_wgs=512", {"FDGS_WGRAD_WGS": "512"}),
+    ("d2_wgs=192", {"FDGS_D2_WGS": "192"}),
+    ("d1_wgs=0", {"FDGS_D1_WGS": "0"}),
+    ("default_again", {}),
 ]
-KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS", "FDGS_WGRAD_TRUNK", "FDGS_SMALL_HEADS")
+KNOBS = ("FDGS_PG_LDS", "FDGS_PG_WGS", "FDGS_D2_WGS", "FDGS_WGRAD_WGS", "FDGS_WGRAD_TRUNK", "FDGS_SMALL_HEADS", "FDGS_D1_WGS")
 
 
 def main():
@@ -50,6 +56,7 @@ def main():
     L = fdgs._lib.lib()
     N, W, H, dcfg = bench.WORKLOADS[args.workload]
     pc = syn.SynthModel(N, dcfg, seed=6666, device=dev)
+    fdgs.densify.spatial_reorder(pc)          # the order the train loop keeps (live-tile lists, windowed plane gradient)
     pipe = syn.PipelineParams()
     bg = torch.zeros(3, device=dev)
     cams = [c.to(dev) for c in syn.orbit_cameras(W, H, n=160)]
