@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
         return a.pair_gid[range.x + (e >= 0 ? e : 0)];
     };
     // (staging the records with global_load_lds_dwordx4 into a second LDS buffer frees their 12 registers -- 90 VGPRs, five waves per
-    // SIMD -- and measured SLOWER, 0.341 vs 0.313 ms: the round-start vmcnt(0) also waits for the round's 64 atomics;
+    // SIMD -- and measured SLOWER, 0.341 vs 0.313 ms: the round-start vmcnt(0) also waits for the round's 64 atomics, and with a
+    // counted wait hipcc still puts a vmcnt(0) in front of every LDS read that may alias an outstanding DMA -- one per list entry;
     // profiles/r03j_bench_cfg4_rbwd_glds.json)
     uint32_t g_cur = gid_of(0), g_nxt = rounds > 1 ? gid_of(1) : 0u;
     float4 rA = a.recA[g_cur], rB = a.recB[g_cur], rC = a.recC[g_cur];
