@@ -104,6 +104,7 @@ struct DeformDev {
     AabbScale sc;
     int F;
     int small_heads;   // 1: k <= 4 heads on the 4x4x1 MFMA (default), 0: padded 32x32x2 tiles (A/B switch, FDGS_SMALL_HEADS)
+    int split_tail;    // 1: the tiles left over after the last full round of the persistent loop are split by head over the waves (FDGS_D1_SPLIT)
     // optional saved activations for the backward (rows < Npad): features [Np][F], relu(hidden) [Np][W], relu(h1) [slot][Np][W]
     float *sv_feat, *sv_rh, *sv_h1;
     int ntiles;                     // 32-Gaussian tiles (a multiple of 4)
@@ -471,6 +472,12 @@ __device__ __forceinline__ int next_head(const int* head_on, int hd) {
     return hd;
 }
 
+__device__ __forceinline__ int next_head_m(unsigned mask, int hd) {
+    hd++;
+    while (hd < FDGS_NUM_HEADS && !((mask >> hd) & 1u)) hd++;
+    return hd;
+}
+
 // ------------------------------------------------------------------------------------------------ D1 forward
 #ifndef FDGS_D1_PD1
 #define FDGS_D1_PD1 2
@@ -512,7 +519,34 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 #else
 #define D1_TICK(ph) do { } while (0)
 #endif
-    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < d.ntiles; tile += gridDim.x * 4) {
+    // Persistent loop: wave w takes tiles w, w + #waves, ...  The tiles left over after the last FULL round would keep a few waves busy
+    // for a whole tile while the others idle (300 k Gaussians: 9 376 tiles on 1 024 waves = 9 full rounds + 160 tiles, 8.4 % of the
+    // kernel).  Where they fit, those tiles are split BY HEAD instead: wave u takes head u % nh of tile u / nh -- every such wave repeats
+    // the gather and the trunk (cheap) and evaluates one head, so the last round lasts about a third of a tile.  The first wave of a tile
+    // ("primary") also writes what is per tile rather than per head: saved features / trunk activations, outputs of switched-off heads.
+    unsigned all_heads = 0u;
+    int nh = 0;
+#pragma unroll
+    for (int i = 0; i < FDGS_NUM_HEADS; i++) if (p.head_on[i]) { all_heads |= 1u << i; nh++; }
+    const int nwaves = (int)gridDim.x * 4, wave_id = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int full_rounds = d.ntiles / nwaves, rem = d.ntiles - full_rounds * nwaves;
+    const bool split = d.split_tail != 0 && nh > 1 && rem > 0 && rem * nh <= nwaves;
+    for (int it = 0; it <= full_rounds; it++) {
+    int tile = it * nwaves + wave_id;
+    unsigned head_mask = all_heads;
+    bool primary = true;
+    if (it == full_rounds) {
+        if (split) {
+            if (wave_id >= rem * nh) break;
+            tile = full_rounds * nwaves + wave_id / nh;
+            int ord = wave_id % nh, hsel = -1;
+            for (int i = 0; i < FDGS_NUM_HEADS; i++) if (p.head_on[i] && ord-- == 0) hsel = i;
+            head_mask = 1u << hsel;
+            primary = wave_id % nh == 0;
+        } else if (tile >= d.ntiles) {
+            break;
+        }
+    }
     int g = g0, h = h0;
     asm volatile("" : "+v"(g), "+v"(h));   // keeps the per-layer weight addresses from being hoisted out of the tile loop
     const size_t tile_n0 = (size_t)tile * 32;       // first Gaussian slot of this wave's tile
@@ -523,7 +557,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     DenseTrunk<FCH, WT, 2> T0;
     T0.setup(p.w0, p.b0, d.F, g, h);
     T0.preload();
-    int hd = next_head(p.head_on, -1);
+    int hd = next_head_m(head_mask, -1);
     DenseIL<WT, WT, true, PD1, false> L1;
     if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
@@ -551,7 +585,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     gather_features<FCH>(p, q, h, feat);
     D1_TICK(1);
     const size_t n_row = (size_t)n_raw;   // saved rows are indexed by the un-clamped Gaussian slot (< Npad)
-    if (d.sv_feat) {
+    if (d.sv_feat && primary) {
 #pragma unroll
         for (int j = 0; j < FCH; j++)
             *reinterpret_cast<float4*>(d.sv_feat + n_row * d.F + 8 * j + 4 * h) =
@@ -574,8 +608,8 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
             reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
         }
     };
-    if (d.sv_rh) park(hid, d.sv_rh + tile_n0 * W);
-    if (d.sv_hmask) {   // the backward's ReLU mask of the trunk output, in its own lane layout: one 16-byte load there
+    if (d.sv_rh && primary) park(hid, d.sv_rh + tile_n0 * W);
+    if (d.sv_hmask && primary) {   // the backward's ReLU mask of the trunk output, in its own lane layout: one 16-byte load there
         uint32_t m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int t = 0; t < WT; t++)
@@ -634,7 +668,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     {
         const f32x16 z = zero16();
         for (int h0 = 0; h0 < FDGS_NUM_HEADS; h0++)
-            if (!p.head_on[h0]) epilogue(h0, z, z);
+            if (!p.head_on[h0] && primary) epilogue(h0, z, z);
     }
 
     D1_TICK(2);
@@ -652,7 +686,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         relu_inplace<WT>(h1);
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
         if (k > 32) { L2b.setup(w2h + 32 * LDW, p.b2[hd] + 32, LDW, k - 32, g, h); L2b.preload(); }
-        const int nxt = next_head(p.head_on, hd);
+        const int nxt = next_head_m(head_mask, hd);
         if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
         f32x16 o0 = zero16(), o1 = zero16();
         D1_TICK(4);
@@ -2325,7 +2359,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     if (p->N == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeformDev d;
-    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1); d.sc = aabb_scale(p);
+    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1); d.split_tail = tunable("FDGS_D1_SPLIT", 1); d.sc = aabb_scale(p);
     {
         const SavedLayout sl = saved_layout(p);
         float* sv = reinterpret_cast<float*>(out->saved);

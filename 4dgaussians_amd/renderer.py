@@ -114,9 +114,11 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
         b = _deformation.backward_prepare(st0, saved[0], saved[1], saved[2], identity_assigned=EPILOGUE_ASSIGN)
         dev = b.d_xyz.device
         f = lambda t: None if t is None else t.float().contiguous()
-        g_means2D = []
+        g_means2D = [None] * nviews
         keep = []
-        for v, (st, rstate) in enumerate(states):
+        # last view first: its saved activations, lists and records are the ones still (partly) resident in the 256 MB Infinity Cache
+        for k_, v in enumerate(reversed(range(nviews))):
+            st, rstate = states[v]
             p = rstate.params
             P = p.P
             gc = f(grad_colors[v]) if grad_colors is not None else torch.zeros(3, p.H, p.W, device=dev)
@@ -130,7 +132,7 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             epi.d_xyz, epi.d_scales, epi.d_rotations, epi.d_opacity = b.g.d_xyz, b.g.d_scales, b.g.d_rotations, b.g.d_opacity
             epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
             epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
-            epi.assign = 1 if (EPILOGUE_ASSIGN and v == 0) else 0        # later views accumulate into what the first one assigned
+            epi.assign = 1 if (EPILOGUE_ASSIGN and k_ == 0) else 0       # later views accumulate into what the first processed one assigned
             epi.tile_flags = 1
             g.deform_epilogue = _lib.ctypes.pointer(epi)
             _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
@@ -141,7 +143,7 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             b.g.packed_rows_ready = 2
             _lib.check(L.fdgs_deform_bwd(_lib.stream_ptr(), st.p, b.g))
             _deformation.note_live_tiles(st, b)
-            g_means2D.append(gm)
+            g_means2D[v] = gm
             keep.append((gc, gd, acc, epi))
         cfg, sh = st0.cfg, st0.shapes
         d_mlp = b.d_mlp
