@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) scan_add_kernel(uint32_t* __restrict__ ds
 }
 
 // ---------------------------------------------------------------- radix histogram: hist[digit*nblocks + block]
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
                                                                   uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t h[RADIX];
     h[threadIdx.x] = 0;
@@ -124,13 +124,17 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++) {
         uint32_t i = base + j * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // ---------------------------------------------------------------- radix scatter (stable)
+// BITS = width of this pass's digit (<= RADIX_BITS): a sort over nbits key bits uses ceil(nbits / 8) passes of near-equal width -- the
+// 13-bit tile sort of a 1352x1014 frame is a 7-bit and a 6-bit pass: 13 instead of 16 ballot rounds per key, and the runs a block
+// writes per digit are 32 / 64 keys long (whole 128-byte lines) instead of 16.
+template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -157,10 +161,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         const bool valid = i < n;
         key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[j] = valid ? vals_in[i] : 0u;
-        const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+        const uint32_t d = (key[j] >> shift) & ((1u << BITS) - 1u);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < RADIX_BITS; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
     for (int j = 0; j < SORT_ITEMS; j++) {
         const uint32_t i = wave_base + j * 64 + lane;
         if (i < n) {
-            const uint32_t d = (key[j] >> shift) & (RADIX - 1);
+            const uint32_t d = (key[j] >> shift) & ((1u << BITS) - 1u);
             const uint32_t pos = lbase[d] + wcnt[w][d] + rank[j];
             skey[pos] = key[j];
             sval[pos] = val[j];
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         const uint32_t li = j * SORT_THREADS + t;
         if (li < block_n) {
             const uint32_t k = skey[li];
-            const uint32_t d = (k >> shift) & (RADIX - 1);
+            const uint32_t d = (k >> shift) & ((1u << BITS) - 1u);
             const uint32_t pos = gbase[d] + (li - lbase[d]);
             keys_out[pos] = k;
             vals_out[pos] = sval[li];
@@ -234,17 +238,29 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
                      uint32_t* hist, int nblocks, int debug, int* result_in) {
     int cur = 0;
     if (n > 0) {
-        for (int shift = 0; shift < nbits; shift += RADIX_BITS) {
+        const int npass = (nbits + RADIX_BITS - 1) / RADIX_BITS;
+        int shift = 0;
+        for (int ps = 0; ps < npass; ps++) {
+            const int bits = nbits / npass + (ps < nbits % npass ? 1 : 0);      // near-equal digit widths (32 -> 8,8,8,8; 13 -> 7,6)
+            const uint32_t mask = (1u << bits) - 1u;
             uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
             uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
-            { FDGS_TIMED("radix_hist", stream); hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, hist, nblocks); }
+            { FDGS_TIMED("radix_hist", stream); hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks); }
             FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
             uint32_t* dtot = hist + (size_t)RADIX * nblocks;  // 256 digit totals live in the slack behind the counters
             { FDGS_TIMED("radix_scan", stream); hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RADIX), dim3(256), 0, stream, hist, nblocks, dtot); }
             FDGS_LAUNCH_CHECK("radix_scan", debug, stream);
-            { FDGS_TIMED("radix_scatter", stream); hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist,
-                               nblocks, dtot); }
+            {
+                FDGS_TIMED("radix_scatter", stream);
+#define FDGS_SCATTER(B_) hipLaunchKernelGGL(radix_scatter_kernel<B_>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot)
+                switch (bits) {
+                    case 1: FDGS_SCATTER(1); break; case 2: FDGS_SCATTER(2); break; case 3: FDGS_SCATTER(3); break; case 4: FDGS_SCATTER(4); break;
+                    case 5: FDGS_SCATTER(5); break; case 6: FDGS_SCATTER(6); break; case 7: FDGS_SCATTER(7); break; default: FDGS_SCATTER(8); break;
+                }
+#undef FDGS_SCATTER
+            }
             FDGS_LAUNCH_CHECK("radix_scatter", debug, stream);
+            shift += bits;
             cur ^= 1;
         }
     }
