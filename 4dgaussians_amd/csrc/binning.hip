@@ -8,8 +8,9 @@
 //       (ceil(log2(#tiles)/8) = 2 passes over R pairs instead of 6, 8 B per pair instead of 12 B).
 // Ties (equal tile, equal depth) resolve by Gaussian index in both formulations because every pass is stable.
 //
-// Radix pass = wave64 ballot ranking (8 ballots per 64 keys give each lane its rank among equal digits), per-wave
-// digit counters in LDS, keys regrouped by digit in LDS so that the global scatter writes contiguous runs.
+// Radix pass = wave64 ballot ranking (one ballot per digit bit gives each lane its rank among equal digits), per-wave
+// digit counters in LDS, keys regrouped by digit in LDS so that the global scatter writes contiguous runs.  A sort over
+// nbits key bits runs ceil(nbits / 8) passes of near-equal digit width (32 -> 8,8,8,8; the 13-bit tile id -> 7,6).
 #include "common.h"
 
 namespace fdgs {

@@ -24,7 +24,10 @@
 //   D4 plane gradients: lanes <-> (x-corner, channel) so that every float atomic instruction covers whole texel lines
 //      (scattered float atomics run at only ~20 G line-ops/s on MI355X: profiles/r01_atomic_microbench.txt); the three
 //      time planes are privatised in LDS.
-// Environment knobs (development / A-B only, defaults are the tuned values): FDGS_SMALL_HEADS, FDGS_USE_SAVED,
+//   Round 3: the backward kernels walk only the 32-Gaussian tiles that carry a non-zero gradient row (tile_compact_kernel turns the
+//      rasterizer backward's per-tile flags into lists: culled / occluded Gaussians add exactly zero to every sum); D1 deals the tiles left
+//      over after the last full round of its persistent loop out by head (FDGS_D1_SPLIT).
+// Environment knobs (development / A-B only, defaults are the tuned values): FDGS_SMALL_HEADS, FDGS_USE_SAVED, FDGS_SKIP_DEAD, FDGS_D1_SPLIT,
 // FDGS_D1_WGS (0 = one workgroup per four tiles instead of the persistent tile loop), FDGS_D2_WGS, FDGS_WGRAD_WGS,
 // FDGS_WGRAD_TRUNK, FDGS_PG_LDS, FDGS_PG_LDS_KB, FDGS_PG_WGS; -DFDGS_PROFILE_D1 / -DFDGS_PROFILE_D2 add an in-kernel
 // s_memtime phase profile of D1 / D2 (printed once to stderr); -DFDGS_DEV_ONLY_44 builds only the (128, 32) instance.

@@ -1,14 +1,14 @@
 // render.hip -- K6 (front-to-back alpha blending) and K7 (its backward) for gfx950.
 //
-// One 256-thread workgroup (4 wave64) per 16x16-pixel tile, one pixel per lane; a wave covers a 16x4 pixel strip.
-// Tiles are handed to XCDs in contiguous bands (workgroup b lands on XCD b%8 -> band b%8) so that the per-Gaussian
-// records a band keeps re-reading stay in that XCD's 4 MiB L2.
-// Per round the workgroup stages 256 list entries (3 x float4 per Gaussian) in LDS; the inner loop reads them with
-// wave-uniform (broadcast) ds_read_b128.
-// Backward: each lane recomputes alpha back-to-front; the per-Gaussian sums over the 64 pixels of a wave are formed
-// with DPP butterflies inside the 16-lane rows plus v_permlane16_swap / v_permlane32_swap across rows (no LDS
-// traffic), skipped entirely when no lane of the wave is hit; the four waves meet in a 10-float LDS slot per staged
-// Gaussian and the tile issues ONE 64-byte atomic line-op per (tile, Gaussian) into a packed [P,16] gradient array.
+// Forward: one 256-thread workgroup (4 wave64) per 16x16-pixel tile, one pixel per lane; per round the workgroup stages 256 list
+// entries (3 x float4 per Gaussian) in LDS and the inner loop reads them with wave-uniform (broadcast) ds_read_b128.
+// Backward (round 3): ONE wave per tile, four pixels per lane as two packed-f32 pairs (render_bwd_strip_kernel): each lane recomputes
+// alpha back-to-front, forms the per-Gaussian sums of its pixels as moments over dy, the wave adds them with a DPP / permlane
+// reduce-scatter and issues ONE 64-byte atomic line-op per (tile, Gaussian) into a packed [P,16] gradient array.  The 256-thread
+// backward of rounds 1-2 (four waves meeting in LDS slots) stays selectable (FDGS_RBWD_PPL=0), as does a strip form of the forward
+// (FDGS_RFWD_PPL, measured slower).
+// Tile rows are dealt to the XCDs in groups (unit_of_block: workgroup b runs on XCD b % 8), so that neighbouring tiles -- which list
+// the same Gaussians -- share an XCD's 4 MiB L2 and every XCD owns rows from the whole height of the image.
 // Replaces renderCUDA forward/backward of the un-vendored rasterizer (Appendix B.3/B.4).
 #include "common.h"
 #include "gs_math.h"
