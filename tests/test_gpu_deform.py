@@ -503,3 +503,31 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     dead = (mask == 0).to(dev)
     for a in res["1"][0][:5]:
         assert float(a[dead].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg,n", [("dynerf_default", 9000), ("hypernerf_default", 5000), ("dynerf_default", 40100)])
+def test_leftover_tiles_split_by_head_changes_nothing(cfg, n, monkeypatch):
+    """D1 deals the tiles left over after the last full round of its persistent loop out BY HEAD (wave u: head u % n_h of tile u / n_h)
+    when leftover x heads fits the launch (FDGS_D1_SPLIT=0: every wave takes whole tiles).  Same arithmetic in the same order per
+    Gaussian, so outputs, saved activations and therefore gradients must be bit-identical.  9 000 / 5 000 Gaussians: every tile is a
+    leftover tile (split active); 40 100: 1 256 tiles = one full round + 232 leftover tiles, which do NOT fit by head (no split)."""
+    dev = torch.device("cuda:0")
+    fd = _fdgs()
+    args, net, ins = _net_and_inputs(cfg, n, 9, dev, safe=False, fixed_time=0.61)
+    net = net.to(dev)
+    ws = [torch.randn(s, generator=torch.Generator().manual_seed(4)).to(dev) for s in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 16, 3))]
+    res = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("FDGS_D1_SPLIT", split)
+        gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
+        out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.61, activate=True)
+        params = [p for _, p in net.named_parameters() if p.requires_grad]
+        g = torch.autograd.grad(sum((o * w).sum() for o, w in zip(out, ws)), gpu_in[:5] + params, allow_unused=True)
+        torch.cuda.synchronize()
+        res[split] = ([o.detach().clone() for o in out], g)
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b) or rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6     # (weight gradients: atomics in launch order)
