@@ -116,14 +116,15 @@ __global__ void __launch_bounds__(256) scan_add_kernel(uint32_t* __restrict__ ds
 }
 
 // ---------------------------------------------------------------- radix histogram: hist[digit*nblocks + block]
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
                                                                   uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t h[RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_CHUNK;
+    const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         uint32_t i = base + j * SORT_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t
 // BITS = width of this pass's digit (<= RADIX_BITS): a sort over nbits key bits uses ceil(nbits / 8) passes of near-equal width -- the
 // 13-bit tile sort of a 1352x1014 frame is a 7-bit and a 6-bit pass: 13 instead of 16 ballot rounds per key, and the runs a block
 // writes per digit are 32 / 64 keys long (whole 128-byte lines) instead of 16.
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
@@ -145,19 +146,20 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
     __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counters
     __shared__ uint32_t lbase[RADIX];     // start of digit d inside the block-local regrouped array
     __shared__ uint32_t gbase[RADIX];     // global start of (digit d, this block)
-    __shared__ uint32_t skey[SORT_CHUNK];
-    __shared__ uint32_t sval[SORT_CHUNK];
+    constexpr int CHUNK = SORT_THREADS * ITEMS;
+    __shared__ uint32_t skey[CHUNK];
+    __shared__ uint32_t sval[CHUNK];
     __shared__ uint32_t wtmp[4];
     __shared__ uint32_t wtmp2[4];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll
     for (int k = 0; k < 4; k++) wcnt[k][t] = 0;
     __syncthreads();
-    const uint32_t wave_base = blockIdx.x * SORT_CHUNK + w * (SORT_CHUNK / 4);
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
-    uint16_t rank[SORT_ITEMS];
+    const uint32_t wave_base = blockIdx.x * CHUNK + w * (CHUNK / 4);
+    uint32_t key[ITEMS], val[ITEMS];
+    uint16_t rank[ITEMS];
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         const uint32_t i = wave_base + j * 64 + lane;
         const bool valid = i < n;
         key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         const uint32_t i = wave_base + j * 64 + lane;
         if (i < n) {
             const uint32_t d = (key[j] >> shift) & ((1u << BITS) - 1u);
@@ -218,10 +220,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         }
     }
     __syncthreads();
-    const uint32_t block_base = blockIdx.x * SORT_CHUNK;
-    const uint32_t block_n = (n - block_base) < (uint32_t)SORT_CHUNK ? (n - block_base) : (uint32_t)SORT_CHUNK;
+    const uint32_t block_base = blockIdx.x * CHUNK;
+    const uint32_t block_n = (n - block_base) < (uint32_t)CHUNK ? (n - block_base) : (uint32_t)CHUNK;
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         const uint32_t li = j * SORT_THREADS + t;
         if (li < block_n) {
             const uint32_t k = skey[li];
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
 // LSD radix sort of n (key,val) pairs over bits [0,nbits). Ping-pongs between (k0,v0) and (k1,v1); returns which
 // buffer holds the result (0 or 1) through *result_in.
 int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, int nbits,
-                     uint32_t* hist, int nblocks, int debug, int* result_in) {
+                     uint32_t* hist, int nblocks, int debug, int* result_in, int items = SORT_ITEMS) {
     int cur = 0;
     if (n > 0) {
         const int npass = (nbits + RADIX_BITS - 1) / RADIX_BITS;
@@ -246,14 +248,22 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
             const uint32_t mask = (1u << bits) - 1u;
             uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
             uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
-            { FDGS_TIMED("radix_hist", stream); hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks); }
+            {
+                FDGS_TIMED("radix_hist", stream);
+                if (items == NSORT_ITEMS) hipLaunchKernelGGL(radix_hist_kernel<NSORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks);
+                else hipLaunchKernelGGL(radix_hist_kernel<SORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks);
+            }
             FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
             uint32_t* dtot = hist + (size_t)RADIX * nblocks;  // 256 digit totals live in the slack behind the counters
             { FDGS_TIMED("radix_scan", stream); hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RADIX), dim3(256), 0, stream, hist, nblocks, dtot); }
             FDGS_LAUNCH_CHECK("radix_scan", debug, stream);
             {
                 FDGS_TIMED("radix_scatter", stream);
-#define FDGS_SCATTER(B_) hipLaunchKernelGGL(radix_scatter_kernel<B_>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot)
+#define FDGS_SCATTER(B_)                                                                                                                  \
+    do {                                                                                                                              \
+        if (items == NSORT_ITEMS) hipLaunchKernelGGL((radix_scatter_kernel<B_, NSORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot); \
+        else hipLaunchKernelGGL((radix_scatter_kernel<B_, SORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot); \
+    } while (0)
                 switch (bits) {
                     case 1: FDGS_SCATTER(1); break; case 2: FDGS_SCATTER(2); break; case 3: FDGS_SCATTER(3); break; case 4: FDGS_SCATTER(4); break;
                     case 5: FDGS_SCATTER(5); break; case 6: FDGS_SCATTER(6); break; case 7: FDGS_SCATTER(7); break; default: FDGS_SCATTER(8); break;
@@ -401,7 +411,7 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(geom, gl.keys0), at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.keys1),
                           at<uint32_t>(geom, gl.ids1), (uint32_t)p->P, 32, at<uint32_t>(geom, gl.hist), gl.sort_blocks, p->debug,
-                          &in);
+                          &in, NSORT_ITEMS);
     if (rc) return rc;
     // 4 passes: result is back in buffer 0
     const uint32_t* sorted_ids = at<uint32_t>(geom, in ? gl.ids1 : gl.ids0);

@@ -87,8 +87,18 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* wt
 
 // ---- radix sort geometry (binning.hip) ----
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;                       // keys per thread
+#ifndef FDGS_RSORT_ITEMS
+#define FDGS_RSORT_ITEMS 16
+#endif
+#ifndef FDGS_NSORT_ITEMS
+#define FDGS_NSORT_ITEMS 4
+#endif
+constexpr int SORT_ITEMS = FDGS_RSORT_ITEMS;         // keys per thread (tile sort of the R pairs)
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS; // 4096 keys per workgroup
+// The depth sort of the P Gaussians uses 1024-key workgroups: at 300 k Gaussians 4096-key blocks are 74 workgroups on 256 CUs, each
+// pass a chain of three latency-bound launches; 293 smaller blocks fill the chip and a block's serial part is four times shorter.
+constexpr int NSORT_ITEMS = FDGS_NSORT_ITEMS;
+constexpr int NSORT_CHUNK = SORT_THREADS * NSORT_ITEMS;
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
@@ -117,7 +127,7 @@ inline GeomLayout geom_layout(int P) {
     g.ids1 = take(n * 4);
     g.offsets = take(n * 4);
     g.cullmask = take(n * 32);   // 256 bits per Gaussian: which tiles of its square can receive a contribution
-    g.sort_blocks = cdiv((long long)n, SORT_CHUNK);
+    g.sort_blocks = cdiv((long long)n, NSORT_CHUNK);
     g.hist = take(((size_t)RADIX * g.sort_blocks + 1024) * 4);
     g.bytes = o;
     return g;
