@@ -221,15 +221,24 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
     float dsh[48];
 #pragma unroll
     for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+    // The blending backward leaves an all-zero line for every Gaussian no pixel blended (behind saturated pixels: most of a dense scene).
+    // Its chain rule is zero times everything: such a Gaussian skips the loads of its position / covariance / SH and the arithmetic and
+    // writes its zero rows -- in spatial order whole waves do.  (Outputs identical: every term carries a factor from the line.)
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+    bool any_grad = false;
     if (active) {
+        const float4* ga = reinterpret_cast<const float4*>(a.gacc + 16 * (size_t)i);
+        g0 = ga[0]; g1 = ga[1]; g2 = ga[2];
+        any_grad = g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f || g1.x != 0.f || g1.y != 0.f || g1.z != 0.f || g1.w != 0.f ||
+                   g2.x != 0.f || g2.y != 0.f;
+    }
+    if (active && any_grad) {
         CamConst c;
         load_cam(c, a.view, a.proj, a.campos, a.W, a.H, a.tanfovx, a.tanfovy, a.scale_mod, a.D, a.M);
         float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
         float c6[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
-        const float4* ga = reinterpret_cast<const float4*>(a.gacc + 16 * (size_t)i);
-        const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
         // mean2D gradient is handed back in NDC units (d pix / d ndc = W/2, H/2), like the reference's viewspace grad
         m2d[0] = g0.x * 0.5f * (float)a.W; m2d[1] = g0.y * 0.5f * (float)a.H;
         dop = g1.y;
