@@ -878,6 +878,7 @@ __device__ __forceinline__ const_u32p as_const(const uint32_t* p) { return (cons
 struct CompactArgs {
     const uint32_t* flags; uint32_t* live; uint32_t* chunks; uint32_t* counters;
     int ntiles, tpc, skip;
+    float* G;      // packed rows: the dead tile used as padding of live[] gets zero rows here (its producer may have left them unwritten)
 };
 __global__ void __launch_bounds__(1024) tile_compact_kernel(CompactArgs a) {
     __shared__ uint32_t wl[16], wc[16];
@@ -930,6 +931,10 @@ __global__ void __launch_bounds__(1024) tile_compact_kernel(CompactArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; j++) if (fv[j]) a.chunks[pc++] = (uint32_t)(i + j);
         }
+    }
+    if (a.skip && a.G && (tl & 3u) != 0u && first_dead != 0xffffffffu) {
+        float* rows = a.G + (size_t)first_dead * 32 * GCOLS;
+        for (int k = t; k < 32 * GCOLS; k += 1024) rows[k] = 0.f;
     }
     if (t == 0) {
         const uint32_t n4 = (tl + 3u) & ~3u;
@@ -2478,7 +2483,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     {
         // tiles with a non-zero gradient row -> lists (packed_rows_ready = 1: rows without flags: every tile counts as live)
         CompactArgs ca{};
-        ca.flags = s.tile_live; ca.live = s.live; ca.chunks = s.chunks; ca.counters = s.counters;
+        ca.flags = s.tile_live; ca.live = s.live; ca.chunks = s.chunks; ca.counters = s.counters; ca.G = s.G;
         ca.ntiles = (int)(Np / 32); ca.tpc = Gc / 32;
         ca.skip = (tunable("FDGS_SKIP_DEAD", 1) != 0 && g->packed_rows_ready != 1) ? 1 : 0;
         { FDGS_TIMED("tile_compact", stream); hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, stream, ca); }

@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
                 row[10] = dop;
             }
         }
+        bool t0_live = true, t1_live = true;     // the wave's two 32-row tiles
         if (e.tile_flags) {
             // per 32-row tile of the deformation backward: does any row carry a gradient at all?  (culled / occluded / off-screen
             // Gaussians do not: fdgs_deform_bwd skips tiles made of them -- a zero row adds exactly zero to every sum)
@@ -298,6 +299,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
                 tl[0] = (uint32_t)(m & 0xffffffffull) != 0u ? 1u : 0u;
                 tl[1] = (uint32_t)(m >> 32) != 0u ? 1u : 0u;
             }
+            if (e.tile_flags == 2) { t0_live = (uint32_t)(m & 0xffffffffull) != 0u; t1_live = (uint32_t)(m >> 32) != 0u; }   // dead tiles' rows stay unwritten
         }
         float* small = buf;              // [64][16]
         float* sh = buf + 64 * 16;       // [64][48]
@@ -314,6 +316,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
             float4* G4 = reinterpret_cast<float4*>(e.G + (size_t)n0 * 64);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
+                if (!(j < 8 ? t0_live : t1_live)) continue;      // (rows 0..31 = pieces 0..7, rows 32..63 = pieces 8..15)
                 const int v = j * 64 + lane, r = v >> 4, c4 = v & 15;
                 G4[v] = c4 < 4 ? reinterpret_cast<const float4*>(small)[r * 4 + c4] : reinterpret_cast<const float4*>(sh)[r * 12 + (c4 - 4)];
             }

@@ -8,6 +8,7 @@ positional-embedding scratch.  With a foreign deformation module (e.g. the refer
 the reference calls it and only the rasterizer is replaced.
 """
 import math
+import os
 
 import torch
 
@@ -61,7 +62,7 @@ class _FusedRenderFunction(torch.autograd.Function):
         epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
         epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
         epi.assign = 1 if EPILOGUE_ASSIGN else 0
-        epi.tile_flags = 1        # per-tile non-zero flags behind the packed rows: the deformation backward skips all-zero tiles
+        epi.tile_flags = 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1      # 2: rows of dead tiles stay unwritten        # per-tile non-zero flags behind the packed rows: the deformation backward skips all-zero tiles
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                      rstate.num_rendered, g))
@@ -133,7 +134,7 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
             epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
             epi.assign = 1 if (EPILOGUE_ASSIGN and k_ == 0) else 0       # later views accumulate into what the first processed one assigned
-            epi.tile_flags = 1
+            epi.tile_flags = 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1      # 2: rows of dead tiles stay unwritten
             g.deform_epilogue = _lib.ctypes.pointer(epi)
             _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                          rstate.num_rendered, g))

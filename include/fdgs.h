@@ -106,7 +106,7 @@ typedef struct fdgs_raster_deform_epilogue {
     int activate;                /* the scales / rotations / opacities the rasterizer received are exp / normalize / sigmoid outputs */
     int Npad;                    /* rows of G: fdgs_deform_bwd's padded Gaussian count (multiple of 128, >= P) */
     const float* rot_norm;       /* [P] norm of the raw quaternion (activate = 1), fdgs_deform_out::rot_norm */
-    float* G;                    /* [Npad,64], every row written (rows >= P zero) */
+    float* G;                    /* [Npad,64], every row written (rows >= P zero) unless tile_flags = 2 */
     float* d_xyz; float* d_scales; float* d_rotations; float* d_opacity;   /* identity paths (any may be NULL) */
     float* d_shs_dc; float* d_shs_rest;                                    /* strides in floats as in fdgs_deform_params */
     int shs_dc_stride; int shs_rest_stride;
@@ -117,7 +117,10 @@ typedef struct fdgs_raster_deform_epilogue {
                                     tile_live[t] = 1 when any of the 32 packed rows 32t .. 32t+31 has a non-zero entry.  Culled, occluded and
                                     off-screen Gaussians get all-zero rows (the reference gives them no gradient either,
                                     gaussian_renderer/__init__.py:134-138); fdgs_deform_bwd (packed_rows_ready = 2) then skips whole tiles of
-                                    them -- bit-exact, a zero row adds exactly zero to every sum */
+                                    them -- bit-exact, a zero row adds exactly zero to every sum.
+                                    2: as 1, and the 32 rows of a tile flagged 0 are NOT written (their content is unspecified): for callers
+                                    that hand G to fdgs_deform_bwd with packed_rows_ready = 2 and tile skipping on, which never reads them
+                                    (the one dead tile it may use as padding is zero-filled there) */
 } fdgs_raster_deform_epilogue;
 
 typedef struct fdgs_raster_grads {
