@@ -190,7 +190,9 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zer
             continue
         sid = stor.setdefault(g.untyped_storage().data_ptr(), len(stor))
         layout.append((sid, g.storage_offset(), g.numel(), str(g.dtype)))
-    sig = hash(tuple(layout)) & 0x3FFFFFFFFFFFFFF
+    # (a digest, not hash(): Python salts str hashes per process, and the signature has to agree ACROSS processes)
+    import hashlib
+    sig = int.from_bytes(hashlib.blake2b(repr(layout).encode(), digest_size=7).digest(), "little")
     s_lo, s_hi = int(sig & 0x3FFFFFFF), int((sig >> 30) & 0x3FFFFFF)
     has = torch.tensor([0 if p_.grad is None else 1 for p_ in params] + [s_lo, s_hi, -s_lo, -s_hi], dtype=torch.int32, device=dev0)
     dist.all_reduce(has, op=dist.ReduceOp.MAX)
