@@ -185,8 +185,11 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zer
     for p_ in params:
         g = p_.grad
         # (dense = numel consecutive elements from storage_offset: row-major, or channels-last like the HexPlane gradients)
-        if g is None or not (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))):
-            layout.append(None)
+        if g is None:
+            layout.append(None)          # no gradient here: fine when that is so on every rank (the signature covers the pattern)
+            continue
+        if not (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))):
+            layout.append("strided")     # cannot be reduced through a flat view of its storage: packing path
             continue
         sid = stor.setdefault(g.untyped_storage().data_ptr(), len(stor))
         layout.append((sid, g.storage_offset(), g.numel(), str(g.dtype)))
@@ -197,7 +200,14 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zer
     has = torch.tensor([0 if p_.grad is None else 1 for p_ in params] + [s_lo, s_hi, -s_lo, -s_hi], dtype=torch.int32, device=dev0)
     dist.all_reduce(has, op=dist.ReduceOp.MAX)
     has = has.tolist()
-    same_layout = all(l is not None for l in layout) and has[-4] == -has[-2] and has[-3] == -has[-1]
+    same_layout = all(l != "strided" for l in layout) and any(l is not None for l in layout) and has[-4] == -has[-2] and has[-3] == -has[-1]
+    # ... and it only pays when it does not multiply the collectives: every dtype's gradients in ONE storage (separately allocated
+    # gradients are better packed into one bucket than reduced one by one)
+    per_dtype = {}
+    for l in layout:
+        if isinstance(l, tuple):
+            per_dtype.setdefault(l[3], set()).add(l[0])
+    same_layout = same_layout and all(len(v) == 1 for v in per_dtype.values())
     has = has[:-4]
     if same_layout and arena_zero_copy:
         # one flat view per storage, spanning its first to its last gradient element (alignment gaps inside the span are reduced
@@ -205,6 +215,8 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zer
         calls = 0
         spans = {}
         for p_, l in zip(params, layout):
+            if l is None:
+                continue                 # (None on every rank, or the signatures would differ)
             lo, hi = spans.get(l[0], (l[1], l[1] + l[2]))
             spans[l[0]] = (min(lo, l[1]), max(hi, l[1] + l[2]))
             spans.setdefault(("t", l[0]), p_.grad)

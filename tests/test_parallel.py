@@ -146,8 +146,11 @@ def _arena_worker(rank, world, port, q):
         return arena, params
 
     arena, params = make(100 + rank)
-    ptr0 = [p_.grad.data_ptr() for p_ in params]
+    params.append(torch.nn.Parameter(torch.zeros(5)))          # no gradient on ANY rank (an unused sub-network): does not stop the in-place path
+    ptr0 = [None if p_.grad is None else p_.grad.data_ptr() for p_ in params]
     calls = par.allreduce_gradients(params)
+    assert params[-1].grad is None
+    params = params[:-1]; ptr0 = ptr0[:-1]
     same_storage = [p_.grad.data_ptr() for p_ in params] == ptr0
     got = [p_.grad.contiguous().clone() for p_ in params]
     # same data through the packing path (zero-copy off) must agree
