@@ -579,7 +579,8 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
     dt = time.perf_counter() - t0
     # outside the timed sample: the float64 re-evaluation of the deformation backward of frame 0 (live rows only) -- the gradient
     # reference that is not itself at the mercy of one ReLU kink (oracle/deform_oracle.py: backward_float64)
-    ref["grads64"] = DO.backward_float64(sd, flags, leaves, cam.time, ref.pop("gouts"))
+    ref["grads64"] = DO.backward_float64(sd, flags, leaves, cam.time, ref["gouts"])
+    ref["ctx"] = (sd, flags, {k: v.detach() for k, v in leaves.items()}, cam.time, ref.pop("gouts"))
     return ({"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s wall on {threads} threads of {cores} host cores; "
                       "deformation = oracle pinned to the reference modules (torch CPU), rasterizer = our C restatement (OpenMP)",
@@ -611,14 +612,18 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
               "f_rest": ["_features_rest"],
               "planes": [k for k in ref["grads"] if "grids" in k and ref["grads"][k] is not None],
               "mlp": [k for k in ref["grads"] if k.startswith("_deformation.") and "grids" not in k and ref["grads"][k] is not None]}
-    grad_rel, grad_rel64 = {}, {}
+    grad_rel = {}
     for gname, keys in groups.items():
         a = np.concatenate([named[k].grad.detach().cpu().numpy().ravel() for k in keys])
         b = np.concatenate([ref["grads"][k].ravel() for k in keys])
         grad_rel[gname] = rel(a, b)
-        if ref.get("grads64"):
-            grad_rel64[gname] = rel(a, np.concatenate([ref["grads64"][k].ravel() for k in keys]))
-    worst_tensor = max(((k, rel(named[k].grad.detach().cpu().numpy(), v)) for k, v in ref["grads"].items()
+    # THE gradient check: against the float64 evaluation of the oracle's deformation backward (same float32 upstream gradients), with the rows on
+    # which the float32 implementation took a near-zero ReLU / texel-cell decision the other way proven, named and attributed (oracle/parity.py)
+    from oracle import parity as OP
+    impl = {k: (named[k].grad.detach().cpu().numpy() if named[k].grad is not None else np.zeros_like(v))
+            for k, v in ref["grads64"].items() if v is not None}
+    att = OP.attribute(*ref["ctx"], impl, ref["grads64"])
+    worst_tensor = max(((k, rel(impl[k], v)) for k, v in ref["grads64"].items()
                         if v is not None and float(np.abs(v).max()) > 0), key=lambda kv: kv[1])
     radii = res["radii"].cpu().numpy()
     return {"frame": "the cpu_baseline frame (same camera, same upstream image gradient)",
@@ -629,17 +634,18 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
             "n_pixels_over_1e-4": int((np.abs(im - ref["color"]).max(axis=0) > 1e-4).sum()), "n_pixels": int(im.shape[1] * im.shape[2]),
             "depth_mean_abs": float(np.abs(dp - ref["depth"]).mean()),
             "radii_mismatch_frac": float((radii != ref["radii"]).mean()),
-            "grad_rel_l2": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},
-            # the same HIP gradients against a float64 evaluation of the oracle's deformation backward (same float32 upstream gradients):
-            # the float32 oracle has the same ReLU / border kinks as any float32 implementation, the per-Gaussian gradient magnitudes are
-            # heavy-tailed, and a single Gaussian rounding to the other side of a kink moves a group's rel-L2 by ~1e-3
-            "grad_rel_l2_vs_float64_oracle": {k: float(f"{v:.3e}") for k, v in grad_rel64.items()},
-            # per group, the closer of the two evaluations of the SAME oracle function: where they disagree with each other (one Gaussian on
-            # a kink), a float32 implementation can only agree with one of them
-            "grad_rel_l2_closer_reference": {k: float(f"{min(v, grad_rel64.get(k, v)):.3e}") for k, v in grad_rel.items()},
+            "grad_rel_l2_vs_float64_oracle": att["grad_rel_l2_vs_float64_raw"],
+            "grad_rel_l2_vs_float64_oracle_kink_rows_attributed": att["grad_rel_l2_vs_float64_kink_rows_attributed"],
+            "kink_rows": att["kink_rows"], "n_kink_rows": att["n_kink_rows"], "max_kink_rows": att["max_kink_rows"],
+            "heavy_rows_within_tol_rowwise": att["heavy_rows_within_tol_rowwise"], "grad_rule": att["rule"],
+            "grad_ok": att["ok"], "grad_failures": att["failures"],
+            # for information: the same HIP gradients against the oracle's own float32 autograd (which has the same kinks as any float32 evaluation)
+            "grad_rel_l2_vs_float32_oracle_info": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},
             "viewspace_rel_l2": float(f"{rel(res['viewspace_points'].grad.cpu().numpy(), ref['means2D']):.3e}"),
             "worst_single_tensor": {"name": worst_tensor[0], "rel_l2": float(f"{worst_tensor[1]:.3e}")},
-            "tolerance": {"image_psnr_dB": ">= 80", "grad_rel_l2": "<= 1e-3 (north_star)"}}
+            "tolerance": {"image_psnr_dB": ">= 80 (our reading of north_star's '1e-4 PSNR': mean squared error <= 1e-8; isolated alpha >= 1/255 "
+                                           "threshold decisions move single pixels by <= 1/255 and are counted in n_pixels_over_1e-4)",
+                          "grad_rel_l2": "<= 1e-3 (north_star) vs the float64 oracle, kink rows attributed row-wise"}}
 
 
 if __name__ == "__main__":

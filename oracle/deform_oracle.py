@@ -23,19 +23,28 @@ HEADS = [("pos_deform", "no_dx", 3), ("scales_deform", "no_ds", 3), ("rotations_
          ("opacity_deform", "no_do", 1), ("shs_deform", "no_dshs", 48)]
 
 
-def _bilinear_border(plane, x, y):
+def _bilinear_border(plane, x, y, dec_x=None, dec_y=None):
     """plane [1,C,Hy,Wx]; x,y in normalised [-1,1] coords ([N]); returns [N,C].
-    pixel = ((coord+1)/2)*(size-1), clamped to [0,size-1]; the clamp has zero gradient outside (0,size-1)."""
+    pixel = ((coord+1)/2)*(size-1), clamped to [0,size-1]; the clamp has zero gradient outside (0,size-1).
+    `dec_x` / `dec_y` (oracle/parity.py only; None = the pinned arithmetic above, untouched): (cell_shift [N] int, gate_flip [N] bool) --
+    evaluate the SAME continuous interpolant from the neighbouring cell (floor + shift: the value and the plane weights are continuous across a
+    cell boundary, the coordinate derivative is not) and / or with the border clamp's derivative gate inverted."""
     _, C, Hy, Wx = plane.shape
 
-    def unnorm(c, size):
+    def unnorm(c, size, dec):
         p = ((c + 1.0) / 2.0) * (size - 1)
         inside = (p > 0) & (p < size - 1)
-        p = torch.where(inside, p, p.detach().clamp(0, size - 1))
-        return p
+        if dec is None:
+            return torch.where(inside, p, p.detach().clamp(0, size - 1))
+        gate = (inside ^ dec[1]).to(p.dtype)
+        return p.detach().clamp(0, size - 1) + (p - p.detach()) * gate       # value clamped as always; derivative gated
 
-    ix, iy = unnorm(x, Wx), unnorm(y, Hy)
+    ix, iy = unnorm(x, Wx, dec_x), unnorm(y, Hy, dec_y)
     x0, y0 = torch.floor(ix.detach()), torch.floor(iy.detach())
+    if dec_x is not None:
+        x0 = x0 + dec_x[0].to(x0.dtype)
+    if dec_y is not None:
+        y0 = y0 + dec_y[0].to(y0.dtype)
     wx1, wy1 = ix - x0, iy - y0
     wx0, wy0 = 1.0 - wx1, 1.0 - wy1
     x0i, y0i = x0.long(), y0.long()
@@ -47,7 +56,7 @@ def _bilinear_border(plane, x, y):
             v11 * (wx1 * wy1)[:, None])
 
 
-def hexplane_features(sd, xyz, t, n_levels, prefix="deformation_net.grid."):
+def hexplane_features(sd, xyz, t, n_levels, prefix="deformation_net.grid.", decisions=None):
     aabb = sd[prefix + "aabb"]
     pts = (xyz - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0
     q = torch.cat([pts, t.reshape(-1, 1)], dim=-1)
@@ -55,7 +64,9 @@ def hexplane_features(sd, xyz, t, n_levels, prefix="deformation_net.grid."):
     for lvl in range(n_levels):
         prod = None
         for k, (i, j) in enumerate(PLANE_PAIRS):
-            v = _bilinear_border(sd[f"{prefix}grids.{lvl}.{k}"], q[:, i], q[:, j])
+            dx = decisions.cell(lvl, i) if decisions is not None else None
+            dy = decisions.cell(lvl, j) if decisions is not None else None
+            v = _bilinear_border(sd[f"{prefix}grids.{lvl}.{k}"], q[:, i], q[:, j], dx, dy)
             prod = v if prod is None else prod * v
         feats.append(prod)
     return torch.cat(feats, dim=-1)
@@ -68,20 +79,57 @@ def count_levels(sd, prefix="deformation_net.grid."):
     return n
 
 
-def deform_forward(sd, flags, xyz, scales, rotations, opacity, shs, t, activate=False):
+class KinkDecisions:
+    """Per-row overrides of the field's derivative discontinuities (ReLU masks, bilinear cell, border-clamp gate) -- used ONLY by
+    oracle/parity.py to evaluate "the same Gaussian with one decision taken the other way"; `deform_forward(decisions=None)` is the
+    pinned arithmetic."""
+
+    def __init__(self, n):
+        self.n = n
+        self.relu_flip = {}      # layer ("trunk" or head name) -> bool [n, width]
+        self.cell_shift = {}     # (level, axis) -> int64 [n]
+        self.gate_flip = {}      # (level, axis) -> bool [n]
+        self.captured = {}       # layer -> (pre-activation, sum |w x| + |b|) of the last forward
+
+    def cell(self, lvl, axis):
+        if (lvl, axis) not in self.cell_shift and (lvl, axis) not in self.gate_flip:
+            return None
+        z = torch.zeros(self.n, dtype=torch.int64)
+        return self.cell_shift.get((lvl, axis), z), self.gate_flip.get((lvl, axis), z.bool())
+
+    def relu(self, layer, x, inp=None, w=None, b=None):
+        if inp is not None:
+            with torch.no_grad():
+                self.captured[layer] = (x.detach().clone(), inp.detach().abs() @ w.detach().abs().t() + b.detach().abs())
+        f = self.relu_flip.get(layer)
+        if f is None:
+            return torch.relu(x)
+        return x * ((x.detach() > 0) ^ f).to(x.dtype)
+
+
+def deform_forward(sd, flags, xyz, scales, rotations, opacity, shs, t, activate=False, decisions=None):
     """sd: reference state_dict (tensors, may require grad); flags: object with no_dx/no_ds/no_dr/no_do/no_dshs.
     Returns (means3D, scales, rotations, opacity, shs) like deform_network.forward; with activate=True the
-    scales/rotations/opacity are passed through exp / normalize(eps 1e-12) / sigmoid."""
-    feat = hexplane_features(sd, xyz, t, count_levels(sd))
-    hidden = F.linear(feat, sd["deformation_net.feature_out.0.weight"], sd["deformation_net.feature_out.0.bias"])
+    scales/rotations/opacity are passed through exp / normalize(eps 1e-12) / sigmoid.
+    `decisions` (a KinkDecisions; oracle/parity.py only) overrides individual ReLU / cell / clamp decisions per row."""
+    feat = hexplane_features(sd, xyz, t, count_levels(sd), decisions=decisions)
+    w0, b0 = sd["deformation_net.feature_out.0.weight"], sd["deformation_net.feature_out.0.bias"]
+    hidden = F.linear(feat, w0, b0)
+    if decisions is None:
+        relu_hidden = lambda: torch.relu(hidden)
+    else:
+        rh = decisions.relu("trunk", hidden, feat, w0, b0)
+        relu_hidden = lambda: rh
     ins = [xyz, scales, rotations, opacity, shs]
     outs = []
     for (name, flag, k), x in zip(HEADS, ins):
         if getattr(flags, flag):
             outs.append(x)
             continue
-        h = F.linear(torch.relu(hidden), sd[f"deformation_net.{name}.1.weight"], sd[f"deformation_net.{name}.1.bias"])
-        d = F.linear(torch.relu(h), sd[f"deformation_net.{name}.3.weight"], sd[f"deformation_net.{name}.3.bias"])
+        w1, b1 = sd[f"deformation_net.{name}.1.weight"], sd[f"deformation_net.{name}.1.bias"]
+        h = F.linear(relu_hidden(), w1, b1)
+        rh1 = torch.relu(h) if decisions is None else decisions.relu(name, h, relu_hidden(), w1, b1)
+        d = F.linear(rh1, sd[f"deformation_net.{name}.3.weight"], sd[f"deformation_net.{name}.3.bias"])
         outs.append(x + d.reshape(x.shape))
     pts, sc, rot, op, sh = outs
     if activate:

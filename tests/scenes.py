@@ -33,13 +33,12 @@ def rel_l2(a, b):
 def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32, both=False):
     """render() restated with the CPU oracles: deformation oracle (pinned to the reference modules) -> C rasterizer oracle
     forward -> L1-loss image gradient against a seeded random target -> C analytic backward -> torch-CPU autograd through the
-    deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, {parameter name: gradient or None}).
+    deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, dL/ddepth, {parameter name: gradient or None}).
     `grad_dtype=torch.float64`: the autograd pass through the deformation is a float64 re-evaluation of the same oracle function fed
-    with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64).  On the 2 M-Gaussian frame the float32
-    autograd of the oracle is itself 1.1e-3 (planes) / 9e-4 (xyz) / 3e-4 (MLP) away from its own float64 evaluation
-    (tools/oracle_f32_vs_f64.py: one Gaussian's ReLU kink) -- more than the tolerance it is meant to check.  `both=True` also returns the
-    float32 autograd gradients under the key "__float32": on a kink the two evaluations disagree with each other and a float32
-    implementation can only agree with one of them."""
+    with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64) -- THE gradient reference of the full-size
+    checks; the returned dict then also carries "__ctx" = (sd, flags, leaves, time, upstream gradients), what oracle.parity.attribute needs
+    to name the rows on which an implementation took a ReLU / texel-cell decision the other way.  `both=True` also returns the float32
+    autograd gradients under "__float32" (tools only)."""
     from oracle import deform_oracle as DO
     from oracle.raster_oracle import RasterOracle
     n = pc._xyz.shape[0]
@@ -70,6 +69,7 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
              torch.tensor(go["opacities"]).reshape(op.shape), torch.tensor(go["shs"]).reshape(sh.shape)]
     if grad_dtype != torch.float32 and stage == "fine":
         grads = DO.backward_float64(sd, pc._deformation.args, leaves, cam.time, gouts)
+        grads["__ctx"] = (sd, pc._deformation.args, {k: v.detach() for k, v in leaves.items()}, cam.time, gouts)
         if both:
             wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
             wnames = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]

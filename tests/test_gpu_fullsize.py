@@ -4,7 +4,9 @@ MLP gradient, the view-space gradient.  The small-size tests exercise one tile r
 loops (9 rounds per CU), the cost-model work split of the weight-gradient kernel, the LDS-privatised time planes at full
 occupancy, the multi-chunk scans and the multi-million-pair sort -- with the numbers looked at.
 
-Tolerances (north_star): image PSNR vs oracle >= 80 dB, gradients <= 1e-3 rel-L2 per parameter group."""
+Tolerances (north_star): image PSNR vs oracle >= 80 dB (our reading of "within 1e-4 PSNR": mean squared error <= 1e-8), gradients <= 1e-3
+rel-L2 per parameter group against ONE reference -- the float64 evaluation of the pinned oracle -- with the rows on which the float32
+implementation took a near-zero ReLU / texel-cell decision the other way proven, named and attributed (oracle/parity.py)."""
 import importlib
 import math
 
@@ -12,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import parity as P
 from scenes import oracle_render_chain, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -45,10 +48,9 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     if order != "random":
         fd.densify.spatial_reorder(pc, curve=order)                # ... in the order bench.py runs it (CPU tensors: torch ops)
     cam = synthetic.orbit_cameras(W, H, n=160)[8]
-    # gradient reference: the oracle's deformation backward evaluated in float64 on the live rows (scenes.oracle_render_chain): its
-    # float32 autograd is, on some frames, itself ~1e-3 off (one Gaussian on a ReLU kink carries the difference)
-    o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth, grad_dtype=torch.float64, both=True)
-    gref32 = gref.pop("__float32")
+    # gradient reference: the oracle's deformation backward evaluated in float64 on the live rows (scenes.oracle_render_chain)
+    o, dc, dd, gref = oracle_render_chain(pc, cam, "fine", target_seed=3, with_depth_grad=with_depth, grad_dtype=torch.float64)
+    ctx = gref.pop("__ctx")
     pc = pc.to(dev)
     res = fd.render(cam.to(dev), pc, synthetic.PipelineParams(), torch.zeros(3, device=dev), stage="fine")
     img = res["render"]
@@ -73,22 +75,18 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     assert n_flip <= int(2e-3 * H * W) and d.max() <= 1.1 / 255.0, (n_flip, float(d.max()))
     assert dmean < 2e-5 and mism < 2e-4
     named = dict(pc.named_parameters())
-    rep = {}
-    for gname, keys in _groups(gref).items():
-        a = np.concatenate([named[k].grad.cpu().numpy().ravel() for k in keys])
-        b = np.concatenate([gref[k].ravel() for k in keys])
-        b32 = np.concatenate([gref32[k].ravel() for k in keys])
-        # the closer of the two evaluations of the oracle (float64 on the live rows / its float32 autograd): where those two disagree
-        # with each other -- one Gaussian on a ReLU kink -- a float32 implementation can only agree with one of them
-        rep[gname] = min(rel_l2(a, b), rel_l2(a, b32))
-    rep["viewspace"] = rel_l2(res["viewspace_points"].grad.cpu().numpy(), gref["__means2D"])
-    per_tensor = {k: rel_l2(named[k].grad.cpu().numpy(), v) for k, v in gref.items()
-                  if not k.startswith("__") and v is not None and float(np.abs(v).max()) > 0}
+    means2D_ref = gref.pop("__means2D")
+    impl = {k: (named[k].grad.cpu().numpy() if named[k].grad is not None else np.zeros_like(v)) for k, v in gref.items() if v is not None}
+    rep = P.attribute(*ctx, impl, gref)
+    vs = rel_l2(res["viewspace_points"].grad.cpu().numpy(), means2D_ref)
+    per_tensor = {k: rel_l2(impl[k], v) for k, v in gref.items() if v is not None and float(np.abs(v).max()) > 0}
     worst = sorted(per_tensor.items(), key=lambda kv: -kv[1])[:4]
-    print("   group rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in rep.items()))
-    print("   worst tensors: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
-    for k, v in rep.items():
-        assert v <= 1e-3, (k, v)
+    print("   group rel-L2 vs float64 oracle (raw): " + ", ".join(f"{k}={v:.2e}" for k, v in rep["grad_rel_l2_vs_float64_raw"].items()) + f", viewspace={vs:.2e}")
+    print("   with kink rows attributed:            " + ", ".join(f"{k}={v:.2e}" for k, v in rep["grad_rel_l2_vs_float64_kink_rows_attributed"].items()))
+    print(f"   kink rows ({rep['n_kink_rows']} of {N}, allowed {rep['max_kink_rows']}): {rep['kink_rows']}  heavy rows: {rep['heavy_rows_within_tol_rowwise']}")
+    print("   worst tensors (raw): " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    assert rep["ok"], rep["failures"]
+    assert vs <= 1e-3, vs
     # parameters of disabled heads / the unused time net get no gradient on either side
     for k, v in gref.items():
         if not k.startswith("__") and (v is None or float(np.abs(v).max()) == 0.0):

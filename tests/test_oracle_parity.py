@@ -1,0 +1,117 @@
+"""oracle/parity.py (gradient parity with per-row kink attribution, the rule the full-size GPU checks and bench.py's parity block
+apply): a float64 evaluation with ONE near-zero ReLU decision taken the other way is attributed to its row and passes; the same
+flip on a unit that is NOT near zero, a scaled row, or too many rows, fail."""
+import importlib
+
+import numpy as np
+import torch
+
+from oracle import deform_oracle as DO
+from oracle import parity as P
+
+synthetic = importlib.import_module("4dgaussians_amd.synthetic")
+
+
+def _scene(n=600, cfg="dynerf_default", seed=5):
+    pc = synthetic.SynthModel(n, cfg, seed=seed)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
+          for k, v in pc._deformation.state_dict().items()}
+    leaves = {k: getattr(pc, k).detach().clone() for k in P.PER_GAUSSIAN}
+    g = torch.Generator().manual_seed(seed)
+    gouts = [torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g), torch.randn(n, 1, generator=g),
+             torch.randn(n, 16, 3, generator=g)]
+    return pc, sd, leaves, gouts
+
+
+def _eval64(sd, flags, leaves, t, gouts, dec=None):
+    """float64 gradients of the whole batch under decision overrides (what an implementation that rounds a kink the other way returns)."""
+    dt = torch.float64
+    sd64 = {k: (v.detach().to(dt).requires_grad_(bool(v.requires_grad)) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    sub = {k: v.detach().to(dt).requires_grad_(True) for k, v in leaves.items()}
+    n = sub["_xyz"].shape[0]
+    outs = DO.deform_forward(sd64, flags, sub["_xyz"], sub["_scaling"], sub["_rotation"], sub["_opacity"],
+                             torch.cat([sub["_features_dc"], sub["_features_rest"]], 1), torch.full((n, 1), t, dtype=dt), activate=True, decisions=dec)
+    wanted = list(sub.values()) + [v for v in sd64.values() if v.dtype.is_floating_point and v.requires_grad]
+    names = list(sub.keys()) + ["_deformation." + k for k, v in sd64.items() if v.dtype.is_floating_point and v.requires_grad]
+    gr = torch.autograd.grad(list(outs), wanted, grad_outputs=[g.to(dt).reshape(o.shape) for g, o in zip(gouts, outs)], allow_unused=True)
+    return {k: (None if x is None else x.numpy()) for k, x in zip(names, gr)}
+
+
+def _put_on_kink(sd, flags, leaves, t, row, unit, layer="trunk"):
+    """Shift the trunk bias so that `unit` of `row` has a pre-activation of rounding size (a float32 evaluation may land on either side)."""
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    n = leaves["_xyz"].shape[0]
+    with torch.no_grad():
+        DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"],
+                          torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1), torch.full((n, 1), t), decisions=dec)
+        sd["deformation_net.feature_out.0.bias"][unit] -= dec.captured[layer][0][row, unit]
+
+
+def test_flipped_near_zero_relu_is_attributed_to_its_row():
+    pc, sd, leaves, gouts = _scene()
+    flags, t, row, unit = pc._deformation.args, 0.37, 123, 17
+    _put_on_kink(sd, flags, leaves, t, row, unit)
+    for g in gouts:
+        g[row] *= 400.0                                   # a heavy-tailed row: its flip alone moves the tensors by > 1e-3
+    ref = DO.backward_float64(sd, flags, {k: v.clone().requires_grad_(True) for k, v in leaves.items()}, t, gouts)
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    dec.relu_flip["trunk"] = torch.zeros(leaves["_xyz"].shape[0], 128, dtype=torch.bool)
+    dec.relu_flip["trunk"][row, unit] = True
+    impl = _eval64(sd, flags, leaves, t, gouts, dec)
+    rep = P.attribute(sd, flags, leaves, t, gouts, impl, ref)
+    print(rep["grad_rel_l2_vs_float64_raw"], rep["kink_rows"])
+    assert max(rep["grad_rel_l2_vs_float64_raw"].values()) > 1e-3          # the raw comparison fails the tolerance ...
+    assert rep["ok"], rep["failures"]                                     # ... the attributed one passes and names the row
+    assert [r["row"] for r in rep["kink_rows"]] == [row] and rep["kink_rows"][0]["matched"] == [f"relu:trunk:{unit}"]
+    assert max(rep["grad_rel_l2_vs_float64_kink_rows_attributed"].values()) < 1e-9
+
+
+def test_flip_away_from_zero_and_plain_errors_fail():
+    pc, sd, leaves, gouts = _scene()
+    flags, t, row = pc._deformation.args, 0.37, 77
+    for g in gouts:
+        g[row] *= 400.0
+    ref = DO.backward_float64(sd, flags, {k: v.clone().requires_grad_(True) for k, v in leaves.items()}, t, gouts)
+    # (a) a ReLU decision flipped where the pre-activation is far from zero: a wrong mask, not a rounding
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    probe = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    n = leaves["_xyz"].shape[0]
+    with torch.no_grad():
+        DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"],
+                          torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1), torch.full((n, 1), t), decisions=probe)
+    unit = int(probe.captured["trunk"][0][row].abs().argmax())
+    dec.relu_flip["trunk"] = torch.zeros(n, 128, dtype=torch.bool)
+    dec.relu_flip["trunk"][row, unit] = True
+    rep = P.attribute(sd, flags, leaves, t, gouts, _eval64(sd, flags, leaves, t, gouts, dec), ref)
+    assert not rep["ok"] and any("no kink" in f for f in rep["failures"]), rep["failures"]
+    # (b) one row off by 1 %
+    impl = {k: (None if v is None else v.copy()) for k, v in ref.items()}
+    impl["_xyz"][row] *= 1.01
+    rep = P.attribute(sd, flags, leaves, t, gouts, impl, ref)
+    assert not rep["ok"], rep
+    # (c) the reference itself passes with nothing to attribute
+    rep = P.attribute(sd, flags, leaves, t, gouts, ref, ref)
+    assert rep["ok"] and rep["n_kink_rows"] == 0
+
+
+def test_cell_boundary_decision_is_attributed():
+    """A Gaussian within rounding of a texel boundary evaluated from the neighbouring cell: same value, other coordinate derivative."""
+    pc, sd, leaves, gouts = _scene(n=400, seed=9)
+    flags, t, row = pc._deformation.args, 0.61, 55
+    aabb = sd["deformation_net.grid.aabb"]
+    with torch.no_grad():       # x of `row` onto texel 20 (+ 2e-6 texel) of the 64-wide level-0 planes
+        c = (20.0 + 2e-6) / 63.0 * 2.0 - 1.0
+        leaves["_xyz"][row, 0] = (c + 1.0) / (2.0 / (aabb[1, 0] - aabb[0, 0])) + aabb[0, 0]
+    for g in gouts:
+        g[row] *= 300.0
+    ref = DO.backward_float64(sd, flags, {k: v.clone().requires_grad_(True) for k, v in leaves.items()}, t, gouts)
+    p = float(((leaves["_xyz"][row, 0].double() - aabb[0, 0].double()) * (2.0 / (aabb[1, 0].double() - aabb[0, 0].double())) - 1.0 + 1.0) / 2.0 * 63)
+    shift = -1 if p - np.floor(p) < 0.5 else +1
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    dec.cell_shift[(0, 0)] = torch.zeros(leaves["_xyz"].shape[0], dtype=torch.int64)
+    dec.cell_shift[(0, 0)][row] = shift
+    impl = _eval64(sd, flags, leaves, t, gouts, dec)
+    rep = P.attribute(sd, flags, leaves, t, gouts, impl, ref)
+    print(rep["grad_rel_l2_vs_float64_raw"], rep["kink_rows"])
+    assert rep["ok"], rep["failures"]
+    assert [r["row"] for r in rep["kink_rows"]] == [row] and rep["kink_rows"][0]["matched"] == [f"cell:(0, 0):{shift}"]
