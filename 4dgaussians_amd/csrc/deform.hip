@@ -876,7 +876,7 @@ __device__ __forceinline__ const_u32p as_const(const uint32_t* p) { return (cons
 //   counters : { live tiles, live tiles padded, live chunks, tiles },
 // and D2 / D3 / D4 walk the lists instead of 0 .. Npad/32.  One workgroup; ~5 us.  skip = 0 lists every tile (A/B, FDGS_SKIP_DEAD=0).
 struct CompactArgs {
-    const uint32_t* flags; uint32_t* live; uint32_t* chunks; uint32_t* counters;
+    uint32_t* flags; uint32_t* live; uint32_t* chunks; uint32_t* counters;    // (skip = 0: flags are WRITTEN here, all ones)
     int ntiles, tpc, skip;
     float* G;      // packed rows: the dead tile used as padding of live[] gets zero rows here (its producer may have left them unwritten)
 };
@@ -891,8 +891,11 @@ __global__ void __launch_bounds__(1024) tile_compact_kernel(CompactArgs a) {
     const int b = t * span, e = b + span < a.ntiles ? b + span : a.ntiles;
     uint32_t nl = 0, nc = 0, fd = 0xffffffffu;
     for (int i = b; i < e; i += 4) {
-        uint4 f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
-        if (!a.skip) f = make_uint4(1u, 1u, 1u, 1u);
+        uint4 f = make_uint4(1u, 1u, 1u, 1u);
+        if (a.skip) f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
+        // every tile is walked: D2 writes every tile's DFEAT rows, and the plane-gradient kernels (which mask DFEAT rows with these flags)
+        // must see them all -- the flags may never have been written (packed_rows_ready = 1) or mark zero rows (harmless either way)
+        else reinterpret_cast<uint4*>(a.flags)[i >> 2] = f;
         const uint32_t fv[4] = {f.x != 0u, f.y != 0u, f.z != 0u, f.w != 0u};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -919,8 +922,8 @@ __global__ void __launch_bounds__(1024) tile_compact_kernel(CompactArgs a) {
         tl += wl[w]; tc += wc[w];
     }
     for (int i = b; i < e; i += 4) {
-        uint4 f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
-        if (!a.skip) f = make_uint4(1u, 1u, 1u, 1u);
+        uint4 f = make_uint4(1u, 1u, 1u, 1u);
+        if (a.skip) f = reinterpret_cast<const uint4*>(a.flags)[i >> 2];
         const uint32_t fv[4] = {f.x != 0u, f.y != 0u, f.z != 0u, f.w != 0u};
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -2481,11 +2484,12 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     const int nwv = tunable("FDGS_D4_WAVES", 8) == 4 ? 4 : 8;
     const int Gc = (nwv == 8 ? 2048 : 1024) / p->C;
     {
-        // tiles with a non-zero gradient row -> lists (packed_rows_ready = 1: rows without flags: every tile counts as live)
+        // tiles with a non-zero gradient row -> lists.  packed_rows_ready = 1: rows without flags -- every tile is live and the kernel writes
+        // the flags (all ones); 3: the rows of dead tiles were never written -- skipping is not a choice then, whatever the A/B knob says
         CompactArgs ca{};
         ca.flags = s.tile_live; ca.live = s.live; ca.chunks = s.chunks; ca.counters = s.counters; ca.G = s.G;
         ca.ntiles = (int)(Np / 32); ca.tpc = Gc / 32;
-        ca.skip = (tunable("FDGS_SKIP_DEAD", 1) != 0 && g->packed_rows_ready != 1) ? 1 : 0;
+        ca.skip = g->packed_rows_ready == 3 ? 1 : ((tunable("FDGS_SKIP_DEAD", 1) != 0 && g->packed_rows_ready != 1) ? 1 : 0);
         { FDGS_TIMED("tile_compact", stream); hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, stream, ca); }
         FDGS_LAUNCH_CHECK("tile_compact", 0, stream);
     }

@@ -101,22 +101,25 @@ def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.
                               ptr(mask8), grad_threshold, dense_size, min_opacity, max_screen_size, max_world_size, ptr(scratch), counts))
     kept, clones, splits = int(counts[0]), int(counts[1]), int(counts[2])
     n_out = kept + clones + 2 * splits
+    # data-parallel replicas must restructure identically.  The plan (kept / clones / splits) is a function of statistics the caller has
+    # already reduced over ranks (parallel.allreduce_densification_stats); it is CHECKED here on every call, before anything depends on it
+    # (a forgotten reduction, a threshold comparison that fell the other way on one rank, or one rank arriving with its own `normals`
+    # would otherwise leave the ranks that do reach the broadcast below blocked until the process-group timeout)
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi:
+        mine = torch.tensor([kept, clones, splits, 1 if normals is None else 0], device=dev, dtype=torch.int64)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"densify: ranks disagree on the plan (kept, clones, splits, samples-drawn-here): min {lo.tolist()} max {hi.tolist()}, "
+                               f"this rank {mine.tolist()} -- reduce the densification statistics over the ranks first "
+                               "(parallel.allreduce_densification_stats)")
     if splits and normals is None:
         normals = torch.randn(2 * splits, 3, device=dev)
-        # data-parallel replicas must split identically: the plan (kept / clones / splits) is a function of statistics the
-        # caller has already reduced over ranks (parallel.allreduce_densification_stats), but the children's positions are
-        # sampled -- rank 0's samples are used everywhere instead of relying on lock-stepped per-rank RNG streams
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # the broadcast needs the same shape on every rank: check the plan first (a forgotten allreduce_densification_stats or a
-            # threshold comparison that fell the other way on one rank would otherwise hang or corrupt memory inside the collective)
-            mine = torch.tensor([kept, clones, splits], device=dev, dtype=torch.int64)
-            lo, hi = mine.clone(), mine.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if not torch.equal(lo, hi):
-                raise RuntimeError(f"densify: ranks disagree on the plan (kept, clones, splits): min {lo.tolist()} max {hi.tolist()}, this rank "
-                                   f"{mine.tolist()} -- reduce the densification statistics over the ranks first (parallel.allreduce_densification_stats)")
+        # the children's positions are sampled: rank 0's samples are used everywhere instead of relying on lock-stepped per-rank RNG streams
+        if multi:
             dist.broadcast(normals, src=0)
     if normals is not None:
         normals = _f32(normals)

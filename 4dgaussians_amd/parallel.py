@@ -47,12 +47,23 @@ def _free_port():
     return port
 
 
+PORT_CLASH_EXIT = 97
+
+
 def _spawn_entry(rank, world, port, fn, args):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
     try:
         fn(*args)
+    except BaseException as e:
+        # a rendezvous port taken between the parent's probe and rank 0's bind is the ONE failure worth a relaunch: it gets its own exit code
+        # (anything else -- an assertion in fn, a bad argument -- must be reported once, not re-executed with its side effects)
+        if "address already in use" in repr(e).lower() or "eaddrinuse" in repr(e).lower():
+            import traceback
+            traceback.print_exc()
+            os._exit(PORT_CLASH_EXIT)
+        raise
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -63,8 +74,8 @@ def spawn_local(world, fn, args=(), poll_s=0.2, attempts=3):
     node, rank r with RANK = LOCAL_RANK = r (-> cuda:r in init_from_env), rendezvous on 127.0.0.1 at a free port, and
     calls fn(*args) in each.  All ranks are polled together: the first non-zero exit terminates the siblings (they would otherwise
     sit in a collective until the process-group timeout) and raises.  The rendezvous port is probed and released before the children
-    bind it; if another process takes it in between, rank 0 dies with "address already in use" within a second and the launch is
-    retried on a new port (`attempts` times).  `fn` must be importable (module-level)."""
+    bind it; if another process takes it in between, the rank that hits "address already in use" exits with PORT_CLASH_EXIT and the launch
+    is retried on a new port (`attempts` times).  Any other failure is reported once.  `fn` must be importable (module-level)."""
     import time
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -72,7 +83,6 @@ def spawn_local(world, fn, args=(), poll_s=0.2, attempts=3):
     for attempt in range(attempts):
         port = _free_port()
         procs = [ctx.Process(target=_spawn_entry, args=(r, world, port, fn, args)) for r in range(world)]
-        t0 = time.monotonic()
         for p in procs:
             p.start()
         bad = []
@@ -93,9 +103,8 @@ def spawn_local(world, fn, args=(), poll_s=0.2, attempts=3):
                 p.kill()
                 p.join(5)
         last = bad
-        # a rank-0 death in the first moments is what a lost rendezvous port looks like: retry on a fresh port; anything later is the
-        # job's own failure
-        if not (time.monotonic() - t0 < 5.0 and any(r == 0 for r, _ in bad)) or attempt == attempts - 1:
+        # only a lost rendezvous port (its own exit code, _spawn_entry) is retried; anything else is the job's own failure
+        if not any(c == PORT_CLASH_EXIT for _, c in bad) or attempt == attempts - 1:
             break
     raise RuntimeError(f"spawn_local: ranks exited non-zero: {last}")
 
@@ -208,6 +217,19 @@ def allreduce_gradients(params, bucket_bytes=512 << 20, average=False, arena_zer
         if isinstance(l, tuple):
             per_dtype.setdefault(l[3], set()).add(l[0])
     same_layout = same_layout and all(len(v) == 1 for v in per_dtype.values())
+    # ... and only when the listed gradients COVER the span that would be reduced: the arena also holds gradients of parameters that are
+    # not in `params` (a caller reducing [xyz, rotation] and then [scaling], or skipping a frozen tensor in the middle), and those must not
+    # be summed -- or divided -- a second time.  Gaps below the arena's 64-element alignment are padding nobody reads.  (A function of the
+    # layout alone, which the digest above has just shown to be the same on every rank: every rank takes the same branch.)
+    if same_layout:
+        by_storage = {}
+        for l in layout:
+            if isinstance(l, tuple):
+                by_storage.setdefault(l[0], []).append((l[1], l[1] + l[2]))
+        for iv in by_storage.values():
+            iv.sort()
+            if any(b0 - a1 >= 64 or b0 < a1 for (_, a1), (b0, _) in zip(iv, iv[1:])):
+                same_layout = False
     has = has[:-4]
     if same_layout and arena_zero_copy:
         # one flat view per storage, spanning its first to its last gradient element (alignment gaps inside the span are reduced

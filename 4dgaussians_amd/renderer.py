@@ -22,6 +22,16 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 # through autograd to a separate packing kernel.  FDGS_FUSED_BACKWARD=0 keeps the two-node form (A/B, and what the tests compare with).
 FUSED_BACKWARD = __import__("os").environ.get("FDGS_FUSED_BACKWARD", "1") != "0"
 EPILOGUE_ASSIGN = True     # False: the epilogue accumulates (+=) into a zero-filled arena (the C-ABI's other mode; tests compare both)
+# fdgs_raster_deform_epilogue::tile_flags of the fused backward.  None = 2 (dead tiles' rows unwritten, always skipped) unless the A/B knob
+# FDGS_SKIP_DEAD=0 asks for every tile to be walked (then 1: flags written, every row written).  0 / 1 / 2 force a mode (tests).
+# The deformation backward is told which mode produced its rows (packed_rows_ready = tile_flags + 1), never the environment alone.
+EPILOGUE_TILE_FLAGS = None
+
+
+def _tile_flags():
+    if EPILOGUE_TILE_FLAGS is not None:
+        return int(EPILOGUE_TILE_FLAGS)
+    return 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1
 
 
 class _FusedRenderFunction(torch.autograd.Function):
@@ -62,11 +72,11 @@ class _FusedRenderFunction(torch.autograd.Function):
         epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
         epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
         epi.assign = 1 if EPILOGUE_ASSIGN else 0
-        epi.tile_flags = 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1      # 2: rows of dead tiles stay unwritten        # per-tile non-zero flags behind the packed rows: the deformation backward skips all-zero tiles
+        epi.tile_flags = _tile_flags()      # per-tile non-zero flags behind the packed rows; 2: rows of dead tiles stay unwritten
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                      rstate.num_rendered, g))
-        b.g.packed_rows_ready = 2
+        b.g.packed_rows_ready = epi.tile_flags + 1
         grads = _deformation.backward_run(st, b)       # (d_xyz, d_sc, d_rot, d_op, d_sha, d_shb, None [time], None [aabb], planes..., mlp...)
         return (None, None, None, g_means2D) + grads[:6] + grads[7:]
 
@@ -134,14 +144,14 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             epi.d_shs_dc, epi.d_shs_rest = b.g.d_shs_dc, b.g.d_shs_rest
             epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
             epi.assign = 1 if (EPILOGUE_ASSIGN and k_ == 0) else 0       # later views accumulate into what the first processed one assigned
-            epi.tile_flags = 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1      # 2: rows of dead tiles stay unwritten
+            epi.tile_flags = _tile_flags()
             g.deform_epilogue = _lib.ctypes.pointer(epi)
             _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                          rstate.num_rendered, g))
             # this view's deformation backward: same output pointers and scratch (stream-ordered reuse), its own saved activations
             b.g.out_scales, b.g.out_rotations, b.g.out_opacity = _lib.ptr(saved[3 * v]), _lib.ptr(saved[3 * v + 1]), _lib.ptr(saved[3 * v + 2])
             b.g.rot_norm, b.g.saved = _lib.ptr(st.o_norm), _lib.ptr(st.saved_act)
-            b.g.packed_rows_ready = 2
+            b.g.packed_rows_ready = epi.tile_flags + 1
             _lib.check(L.fdgs_deform_bwd(_lib.stream_ptr(), st.p, b.g))
             _deformation.note_live_tiles(st, b)
             g_means2D[v] = gm

@@ -100,7 +100,8 @@ int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom,
  * (columns 0-2 position, 3-5 log-scale, 6-9 raw quaternion, 10 opacity logit, 16-63 SH; activation Jacobians of
  * gaussian_renderer/__init__.py:97-99 applied when `activate`) and the identity paths of `out = in + delta` accumulated into the
  * parameter gradients -- instead of dL_dmeans3D / dL_dscales / dL_drotations / dL_dopacity / dL_dsh, which are then not written.
- * G is the START of the scratch buffer later handed to fdgs_deform_bwd (fdgs_deform_grads::scratch) with packed_rows_ready = 1.
+ * G is the START of the scratch buffer later handed to fdgs_deform_bwd (fdgs_deform_grads::scratch) with packed_rows_ready = 1 / 2 / 3
+ * for tile_flags = 0 / 1 / 2.
  * Saves one kernel and a write + read of 236 bytes per Gaussian between the two backward stages. */
 typedef struct fdgs_raster_deform_epilogue {
     int activate;                /* the scales / rotations / opacities the rasterizer received are exp / normalize / sigmoid outputs */
@@ -118,9 +119,10 @@ typedef struct fdgs_raster_deform_epilogue {
                                     off-screen Gaussians get all-zero rows (the reference gives them no gradient either,
                                     gaussian_renderer/__init__.py:134-138); fdgs_deform_bwd (packed_rows_ready = 2) then skips whole tiles of
                                     them -- bit-exact, a zero row adds exactly zero to every sum.
-                                    2: as 1, and the 32 rows of a tile flagged 0 are NOT written (their content is unspecified): for callers
-                                    that hand G to fdgs_deform_bwd with packed_rows_ready = 2 and tile skipping on, which never reads them
-                                    (the one dead tile it may use as padding is zero-filled there) */
+                                    2: as 1, and the 32 rows of a tile flagged 0 are NOT written (their content is unspecified): the caller
+                                    MUST hand G to fdgs_deform_bwd with packed_rows_ready = 3, which never reads them (the one dead tile it
+                                    may use as padding is zero-filled there).
+                                    0: no flags (packed_rows_ready = 1: fdgs_deform_bwd walks every tile) */
 } fdgs_raster_deform_epilogue;
 
 typedef struct fdgs_raster_grads {
@@ -231,9 +233,12 @@ typedef struct fdgs_deform_grads {
     void* scratch;
     /* opt: the `saved` buffer the forward of the SAME parameters / inputs filled (NULL: everything is recomputed) */
     const void* saved;
-    /* 1: `scratch` already starts with the packed gradient rows and the identity paths were applied (fdgs_raster_bwd's epilogue);
-     * the g_* / out_* / rot_norm pointers above are then ignored.  2: as 1, and the rows are followed by the per-tile non-zero flags
-     * (fdgs_raster_deform_epilogue::tile_flags).  0: fdgs_deform_bwd packs the rows (and computes the flags) itself. */
+    /* 0: fdgs_deform_bwd packs the rows (and computes the per-tile flags) itself.
+     * 1: `scratch` already starts with the packed gradient rows and the identity paths were applied (fdgs_raster_bwd's epilogue,
+     *    tile_flags = 0); the g_* / out_* / rot_norm pointers above are then ignored.  No flags: every tile is walked.
+     * 2: as 1, and the rows are followed by the per-tile non-zero flags (epilogue tile_flags = 1): all-zero tiles are skipped.
+     * 3: as 2, and the rows of tiles flagged 0 were NOT written (epilogue tile_flags = 2): all-zero tiles are ALWAYS skipped.
+     * (The development knob FDGS_SKIP_DEAD=0 makes modes 0 and 2 walk every tile for A/B runs; it cannot affect modes 1 and 3.) */
     int packed_rows_ready;
     /* hint, never needed for correctness: 1 = consecutive Gaussians are spatial neighbours (the set is kept along a space-filling
      * curve, fdgs.densify.spatial_reorder): with one frame time for all Gaussians the plane gradient then runs as the windowed

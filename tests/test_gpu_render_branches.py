@@ -304,3 +304,18 @@ def test_backward_skips_tiles_the_rasterizer_gave_no_gradient(monkeypatch):
         e = rel_l2(runs["1"][1][k].cpu().numpy(), runs["0"][1][k].cpu().numpy())
         assert e < 2e-6, (k, e)
     assert rel_l2(runs["1"][2].cpu().numpy(), runs["0"][2].cpu().numpy()) < 2e-6      # (blending atomics: order differs run to run)
+    # packed_rows_ready = 1 (epilogue tile_flags = 0: rows without flags) and 2 (flags, every row written): the C-ABI's other two modes.
+    # Mode 1 once read per-tile flags nothing had written: the scratch block is recycled by the caching allocator, so a
+    # backward of ANOTHER camera in skip mode first leaves that camera's 0 / 1 flags where mode 1 would have looked
+    monkeypatch.setenv("FDGS_SKIP_DEAD", "1")
+    other = synthetic.make_camera(320, 240, theta_deg=200.0, time=0.6, radius=1.2).to(dev)
+    for mode in (0, 1):
+        _render_and_grads(pc, other, _Pipe(), "fine", w)
+        monkeypatch.setattr(fd.renderer, "EPILOGUE_TILE_FLAGS", mode)
+        res, g, v = _render_and_grads(pc, cam, _Pipe(), "fine", w)
+        monkeypatch.setattr(fd.renderer, "EPILOGUE_TILE_FLAGS", None)
+        if mode == 0:
+            assert fd.deformation.last_live_tiles[0] == total
+        for k in runs["0"][1]:
+            e = rel_l2(g[k].cpu().numpy(), runs["0"][1][k].cpu().numpy())
+            assert e < 2e-6, (mode, k, e)

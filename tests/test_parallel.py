@@ -162,7 +162,15 @@ def _arena_worker(rank, world, port, q):
     if rank == 1:
         params3[3].grad = None
     calls3 = par.allreduce_gradients(params3)
-    q.put((rank, calls, same_storage, calls2, agree, calls3, [g_.tolist() for g_ in got], params3[3].grad.tolist(), params3[0].grad.tolist()))
+    # a SUBSET of the arena's gradients (the caller reduces the others separately, or not at all): the tensor in the middle must not be
+    # touched by this call -- the zero-copy span would have summed (and, with average=True, divided) it along with its neighbours
+    arena4, params4 = make(100 + rank)
+    middle_before = params4[1].grad.clone()
+    par.allreduce_gradients([params4[0]] + params4[2:], average=True)
+    middle_untouched = bool(torch.equal(params4[1].grad, middle_before))
+    par.allreduce_gradients([params4[1]], average=True)
+    q.put((rank, calls, same_storage, calls2, agree, calls3, [g_.tolist() for g_ in got], params3[3].grad.tolist(), params3[0].grad.tolist(),
+           middle_untouched, params4[1].grad.tolist(), params4[2].grad.contiguous().tolist()))
     torch.distributed.destroy_process_group()
 
 
@@ -194,6 +202,9 @@ def test_two_rank_gradient_allreduce_runs_in_place_on_the_gradient_arena():
             assert torch.allclose(torch.tensor(got), w, atol=1e-6)
         assert torch.allclose(torch.tensor(r[7]), first[3], atol=1e-6)       # only rank 0 had this one: sum = rank 0's values
         assert torch.allclose(torch.tensor(r[8]), want[0], atol=1e-6)
+        assert r[9] is True                                                   # subset call left the tensor in the middle alone ...
+        assert torch.allclose(torch.tensor(r[10]), want[1] / 2, atol=1e-6)    # ... which was then averaged exactly once
+        assert torch.allclose(torch.tensor(r[11]), want[2] / 2, atol=1e-6)
 
 
 def test_single_process_is_a_noop():
