@@ -17,13 +17,15 @@ class RasterParams(Structure):
                 ("tanfovx", c_float), ("tanfovy", c_float), ("scale_modifier", c_float), ("prefiltered", c_int),
                 ("debug", c_int), ("bg", c_void_p), ("viewmatrix", c_void_p), ("projmatrix", c_void_p),
                 ("campos", c_void_p), ("means3D", c_void_p), ("shs", c_void_p), ("colors_precomp", c_void_p),
-                ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p)]
+                ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p),
+                ("visibility", c_void_p)]
 
 
 class RasterDeformEpilogue(Structure):
     _fields_ = [("activate", c_int), ("Npad", c_int), ("rot_norm", c_void_p), ("G", c_void_p), ("d_xyz", c_void_p),
                 ("d_scales", c_void_p), ("d_rotations", c_void_p), ("d_opacity", c_void_p), ("d_shs_dc", c_void_p),
-                ("d_shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int), ("assign", c_int), ("tile_flags", c_int)]
+                ("d_shs_rest", c_void_p), ("shs_dc_stride", c_int), ("shs_rest_stride", c_int), ("assign", c_int), ("tile_flags", c_int),
+                ("zero_fill", c_void_p), ("zero_floats", c_size_t)]
 
 
 class RasterGrads(Structure):

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, size_t n4, cons
 using namespace fdgs;
 
 extern "C" const char* fdgs_last_error(void) { return g_err; }
-extern "C" int fdgs_abi_version(void) { return 2; }
+extern "C" int fdgs_abi_version(void) { return 3; }
 
 extern "C" int fdgs_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(g_tmu);

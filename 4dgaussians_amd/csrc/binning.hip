@@ -313,7 +313,9 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
                                                            const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect,
                                                            const uint4* __restrict__ cullmask, const uint32_t* __restrict__ total,
                                                            int gx, uint32_t* __restrict__ pair_tile,
-                                                           uint32_t* __restrict__ pair_gid) {
+                                                           uint32_t* __restrict__ pair_gid, uint32_t* __restrict__ ranges_zero, uint32_t ranges_n) {
+    // (the per-tile ranges tile_ranges_kernel fills at the end of the stage: cleared here, on the way, instead of by a memset node)
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ranges_n; k += gridDim.x * 256) ranges_zero[k] = 0u;
     __shared__ uint32_t s_end[256];
     __shared__ uint32_t s_gid[256];
     __shared__ uint2 s_rect[256];
@@ -445,14 +447,16 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     FDGS_REQUIRE(geom && img && (binning || R == 0), "geom/binning/img is NULL");
     hipStream_t stream = (hipStream_t)stream_;
     ImgLayout il = img_layout(p->W, p->H);
-    FDGS_HIP_CHECK(hipMemsetAsync(at<char>(img, il.ranges), 0, (size_t)il.gx * il.gy * 8, stream));
-    if (p->P == 0 || R == 0) return FDGS_OK;
+    if (p->P == 0 || R == 0) {
+        FDGS_HIP_CHECK(hipMemsetAsync(at<char>(img, il.ranges), 0, (size_t)il.gx * il.gy * 8, stream));
+        return FDGS_OK;
+    }
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
     { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
                        at<uint32_t>(geom, gl.total), il.gx,
-                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0)); }
+                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2)); }
     FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.tile1),

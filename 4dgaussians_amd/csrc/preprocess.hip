@@ -29,6 +29,7 @@ struct PreFwdArgs {
     float* depth; float4 *recA, *recB, *recC; float* cov3D;
     uint32_t *tiles, *clamped; uint2* rect; uint32_t *keys, *ids, *total;
     int32_t* radii;
+    uint8_t* visibility;         // opt: radii > 0
     int cull; uint4* cullmask;   // exact tile culling (gs_math.h): 256-bit tile mask per Gaussian, two uint4 each
 };
 
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
         }
         a.tiles[i] = my_tiles;
         a.radii[i] = radius;
+        if (a.visibility) a.visibility[i] = radius > 0 ? 1 : 0;
         a.keys[i] = key;
         a.ids[i] = (uint32_t)i;
     }
@@ -186,6 +188,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* buf = lds_all + wave * 64 * (EPI ? 64 : 48);
     const int n0 = (blockIdx.x * 4 + wave) * 64;
+    if constexpr (EPI) {
+        // zero fill of the caller's accumulate-into gradient range (planes, MLP) on the way: grid-stride float4 stores
+        if (a.epi.zero_fill) {
+            const size_t n4 = a.epi.zero_floats >> 2, stride = (size_t)gridDim.x * 256;
+            for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += stride)
+                reinterpret_cast<float4*>(a.epi.zero_fill)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (n0 >= (EPI ? a.epi.Npad : a.P)) return;
     const int i = n0 + lane;
     const int nvalid = a.P - n0 < 64 ? (a.P - n0 > 0 ? a.P - n0 : 0) : 64;
@@ -470,7 +480,7 @@ extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, v
     a.depth = at<float>(geom, gl.depth); a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB);
     a.recC = at<float4>(geom, gl.recC); a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles);
     a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
-    a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii;
+    a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii; a.visibility = p->visibility;
     a.cull = tunable("FDGS_TILE_CULL", 1) != 0; a.cullmask = at<uint4>(geom, gl.cullmask);
     { FDGS_TIMED("preprocess_fwd", stream); hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
@@ -497,6 +507,8 @@ int fdgs_launch_preprocess_bwd(hipStream_t stream, const fdgs_raster_params* p, 
         FDGS_REQUIRE(p->shs && p->sh_coeffs == 16 && p->scales && p->rotations && !p->cov3D_precomp,
                      "deform_epilogue needs SH (16 coefficients) and scale/rotation inputs");
         FDGS_REQUIRE(e->G && e->Npad >= p->P && e->Npad % 128 == 0 && (!e->activate || e->rot_norm), "bad deform_epilogue");
+        FDGS_REQUIRE(!e->zero_fill || ((reinterpret_cast<uintptr_t>(e->zero_fill) & 15) == 0 && (e->zero_floats & 3) == 0),
+                     "deform_epilogue.zero_fill must be 16-byte aligned with a multiple of 4 floats");
         a.epi = *e;
         { FDGS_TIMED("preprocess_bwd", stream); hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(cdiv(e->Npad, 256)), dim3(256), 0, stream, a); }
         FDGS_LAUNCH_CHECK("preprocess_bwd", p->debug, stream);

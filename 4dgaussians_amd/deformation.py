@@ -366,10 +366,12 @@ class _BwdBuffers:
     __slots__ = ("g", "arena", "d_xyz", "d_sc", "d_rot", "d_op", "d_sha", "d_shb", "d_planes", "d_mlp", "scratch", "keep")
 
 
-def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False):
+def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False, zero_by_epilogue=False):
     """Allocates the gradient arena and the scratch of fdgs_deform_bwd and fills fdgs_deform_grads (without the upstream gradients).
     The arena is zero-filled (every kernel accumulates); with `identity_assigned` the six per-Gaussian arrays at its head are left
-    uninitialised -- the rasterizer backward's epilogue ASSIGNS them (fdgs_raster_deform_epilogue::assign) before anything adds to them.
+    uninitialised -- the rasterizer backward's epilogue ASSIGNS them (fdgs_raster_deform_epilogue::assign) before anything adds to them;
+    with `zero_by_epilogue` (needs `identity_assigned`) the rest (planes, MLP) is not filled here either: `b.zero_range` = (pointer, floats)
+    goes into fdgs_raster_deform_epilogue::zero_fill and that kernel clears it on the way (one fill launch per frame less).
     Returns the buffers; `backward_run` launches."""
     L = _lib.lib()
     cfg, p = st.cfg, st.p
@@ -386,9 +388,14 @@ def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False):
     shapes += [(1, s_[2], s_[3], s_[1]) for s_ in st.plane_shapes]          # channels-last memory order
     shapes += [tuple(m.shape) for m in mlp]
     sizes = [(int(torch.Size(s_).numel()) + 63) // 64 * 64 for s_ in shapes]  # 256-B aligned slices
+    b.zero_range = None
     if identity_assigned:
         arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
-        arena[sum(sizes[:n_fixed]):].zero_()
+        head = sum(sizes[:n_fixed])
+        if zero_by_epilogue:
+            b.zero_range = (arena.data_ptr() + 4 * head, sum(sizes) - head)
+        else:
+            arena[head:].zero_()
     else:
         arena = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
     views, off = [], 0

@@ -127,6 +127,46 @@ def gather_floats(value, device):
     return [float(value)]
 
 
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable objects: device identities, per-rank statistics)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    return [obj]
+
+
+def device_identity(device):
+    """What proves which physical GPU a rank ran on: UUID and PCI bus id where the runtime reports them, plus name and LOCAL_RANK."""
+    ident = {"device": str(device), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        ident["name"] = pr.name
+        for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+            v = getattr(pr, k, None)
+            if v is not None:
+                ident[k] = str(v)
+    return ident
+
+
+def allreduce_latency_us(device, iters=50):
+    """Blocking latency of the path's only collective (the 3-float loss-statistics all-reduce), mean of `iters` after 5 warm-ups, MAX over
+    ranks.  In the timed steps it runs asynchronously under the next frame; this is what it would cost on the critical path."""
+    import time
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return None
+    t = torch.zeros(3, device=device)
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+    for _ in range(5):
+        dist.all_reduce(t)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(t)
+    sync()
+    return max_over_ranks((time.perf_counter() - t0) / iters * 1e6, device)
+
+
 def frames_for_rank(n_frames_total, step, rank, world):
     """Index of the frame rank `rank` renders at step `step` (round-robin over a camera list)."""
     return (step * world + rank) % n_frames_total

@@ -38,6 +38,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 _pinned = {}
+last_num_rendered = 0
 
 
 def _pinned_u32(device):
@@ -63,7 +64,7 @@ def _none_if_empty(t):
 
 class RasterState:
     """Buffers one forward pass leaves behind for its backward (the reference's geom/binning/img buffers)."""
-    __slots__ = ("params", "geom", "binning", "img", "num_rendered", "keep")
+    __slots__ = ("params", "geom", "binning", "img", "num_rendered", "keep", "visibility")
 
 
 def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None):
@@ -106,17 +107,22 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    vis = torch.empty(P, dtype=torch.bool, device=dev)       # radii > 0, written by the projection kernel (no elementwise launch)
+    p.visibility = ptr(vis)
     st = stream_ptr()
     check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
     host = _pinned_u32(dev)
     check(L.fdgs_bin_prepare(st, p, ptr(geom), _lib.c_void_p(host.data_ptr())))
     R = int(host.item()) & 0xFFFFFFFF
+    global last_num_rendered
+    last_num_rendered = R                 # (diagnostics: bench.py reports it per scene)
     check(L.fdgs_binning_bytes(R, W, H, nbytes))
     binning = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     check(L.fdgs_bin_sort(st, p, ptr(geom), ptr(binning), ptr(img), R))
     check(L.fdgs_render_fwd(st, p, ptr(geom), ptr(binning), ptr(img), R, ptr(color), ptr(depth)))
     state = RasterState()
     state.params, state.geom, state.binning, state.img, state.num_rendered = p, geom, binning, img, R
+    state.visibility = vis
     state.keep = (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, bg, view, proj, campos)
     return color, radii, depth, state
 

@@ -43,19 +43,20 @@ class _FusedRenderFunction(torch.autograd.Function):
         ctx.st, ctx.rstate = st, rstate
         ctx.save_for_backward(st.o_sc, st.o_rot, st.o_op)       # (see _DeformFunction.forward: no reference cycle through ctx)
         st.o_xyz = st.o_sc = st.o_rot = st.o_op = st.o_sh = None
-        ctx.mark_non_differentiable(radii)
+        vis = rstate.visibility                                 # radii > 0, written by the projection kernel itself
+        ctx.mark_non_differentiable(radii, vis)
         ctx.set_materialize_grads(False)
-        return color, radii, depth
+        return color, radii, depth, vis
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii, grad_depth):
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_vis=None):
         st, rstate = ctx.st, ctx.rstate
         n_in = 11 + len(st.plane_shapes) + len(st.keep[0][8])
         if grad_color is None and grad_depth is None:
             return (None,) * n_in
         L = _lib.lib()
         o_sc, o_rot, o_op = ctx.saved_tensors
-        b = _deformation.backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=EPILOGUE_ASSIGN)
+        b = _deformation.backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=EPILOGUE_ASSIGN, zero_by_epilogue=EPILOGUE_ASSIGN)
         p = rstate.params
         dev, P = b.d_xyz.device, p.P
         if grad_color is None:
@@ -73,6 +74,8 @@ class _FusedRenderFunction(torch.autograd.Function):
         epi.shs_dc_stride, epi.shs_rest_stride = st.p.shs_dc_stride, st.p.shs_rest_stride
         epi.assign = 1 if EPILOGUE_ASSIGN else 0
         epi.tile_flags = _tile_flags()      # per-tile non-zero flags behind the packed rows; 2: rows of dead tiles stay unwritten
+        if b.zero_range is not None:        # the accumulate-into part of the gradient arena is cleared by the epilogue kernel on the way
+            epi.zero_fill, epi.zero_floats = b.zero_range
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
                                      rstate.num_rendered, g))
@@ -190,7 +193,7 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, st
             times.append(float(cam["time"]))
     if len({(s_.image_height, s_.image_width) for s_ in settings}) != 1:
         return [render(c, pc, pipe, bg_color, scaling_modifier, None, stage, cam_type) for c in cams]
-    sinks = [torch.zeros_like(means3D, requires_grad=True) for _ in cams]
+    sinks = [_zero_leaf(means3D) for _ in cams]
     net = pc._deformation
     planes, mlp = _deformation._collect(net)
     dn = net.deformation_net
@@ -203,6 +206,22 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, st
             for v in range(len(cams))]
 
 
+_zero_pool = {}
+
+
+def _zero_leaf(like):
+    """A fresh LEAF of zeros shaped like `like` without a fill launch per frame: every frame's leaf is a detached alias of one cached,
+    never-written zero buffer per (shape, dtype, device) -- the values are only ever read (the rasterizer ignores them, as the reference's
+    does), the gradient arrives in the leaf's own `.grad`."""
+    key = (tuple(like.shape), like.dtype, like.device)
+    z = _zero_pool.get(key)
+    if z is None:
+        if len(_zero_pool) > 8:
+            _zero_pool.clear()
+        z = _zero_pool[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return z.detach().requires_grad_(True)
+
+
 def _dev(t, device):
     return t if t.device == device else t.to(device, non_blocking=True)
 
@@ -213,7 +232,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     # gradient sink for the screen-space means (train.py:223-225 reads .grad of this tensor).  A LEAF of zeros: the reference's
     # `zeros_like(...) + 0` with retain_grad() costs an extra add kernel per frame plus a clone of the gradient in the retain hook;
     # a leaf's .grad is filled by AccumulateGrad directly (same values, same attribute, read the same way by the train loop)
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=device)
+    screenspace_points = _zero_leaf(means3D)
     if cam_type != "PanopticSports":
         tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
         tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
@@ -253,10 +272,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                        head_on=_deformation._head_on(dn.args), activate=True,
                        save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()),
                        ordered=_deformation.spatial_order_hint(pc._xyz))
-            rendered_image, radii, depth = _FusedRenderFunction.apply(
+            rendered_image, radii, depth, vis = _FusedRenderFunction.apply(
                 cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
                 dn.grid.aabb, *planes, *mlp)
-            return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": vis,
                     "radii": radii, "depth": depth}
         elif fused:
             means3D_final, scales_final, rotations_final, opacity_final, shs_final = _deformation.deform(

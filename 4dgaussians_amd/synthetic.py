@@ -88,16 +88,36 @@ def orbit_cameras(width, height, n=160, n_times=None):
     return [make_camera(width, height, float(th), float(t)) for th, t in zip(thetas, times)]
 
 
-def make_gaussians(n, seed=6666, sh_degree=3, extent=1.3, device="cpu"):
+SHELL_RADII = (0.75, 1.0, 1.25)       # scene="shell": three concentric spheres (x the extent), thin (sigma 0.01)
+SHELL_OPACITY = (0.02, 0.2)          # ... of translucent splats: U(0.02, 0.2)
+SHELL_SCALE = 0.5                     # ... half the cube scene's footprint
+
+
+def make_gaussians(n, seed=6666, sh_degree=3, extent=1.3, device="cpu", scene="cube"):
     """Canonical Gaussians as the reference stores them (scene/gaussian_model.py:137-164 layout):
     xyz [N,3], log-scales [N,3], raw quaternions [N,4] (w first), opacity logits [N,1], features_dc [N,1,3],
-    features_rest [N,15,3]."""
+    features_rest [N,15,3].
+    scene="cube" is SURVEY 8d's generator (uniform in a cube, opacity U(0.05, 0.95)): a volume that occludes itself -- most of its visible
+    Gaussians sit behind saturated pixels and receive no gradient.  scene="shell" is the other regime a trained model can be in:
+    surface-like (three thin concentric spheres), translucent (opacity U(0.02, 0.2)), smaller splats -- nearly every visible Gaussian is
+    blended by some pixel and receives a gradient, so the deformation backward has no dead tiles to skip."""
     g = torch.Generator().manual_seed(seed)
-    xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * extent
-    base = math.log(0.5 * 2 * extent * n ** (-1.0 / 3.0))
+    if scene == "cube":
+        xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * extent
+    elif scene == "shell":
+        d = torch.randn(n, 3, generator=g)
+        d = d / d.norm(dim=1, keepdim=True)
+        r = torch.tensor(SHELL_RADII)[torch.randint(0, len(SHELL_RADII), (n,), generator=g)] * extent
+        xyz = d * (r + 0.01 * torch.randn(n, generator=g))[:, None]
+    else:
+        raise ValueError(f"unknown synthetic scene {scene!r}")
+    base = math.log(0.5 * 2 * extent * n ** (-1.0 / 3.0) * (SHELL_SCALE if scene == "shell" else 1.0))
     scaling = base + 0.3 * torch.randn(n, 3, generator=g)
     rotation = torch.randn(n, 4, generator=g)
-    u = torch.rand(n, 1, generator=g) * 0.9 + 0.05
+    if scene == "shell":
+        u = torch.rand(n, 1, generator=g) * (SHELL_OPACITY[1] - SHELL_OPACITY[0]) + SHELL_OPACITY[0]
+    else:
+        u = torch.rand(n, 1, generator=g) * 0.9 + 0.05
     opacity = torch.log(u / (1 - u))
     dc = ((torch.rand(n, 1, 3, generator=g) - 0.5) / SH_C0)
     rest = 0.05 * torch.randn(n, (sh_degree + 1) ** 2 - 1, 3, generator=g)
@@ -143,10 +163,10 @@ class SynthModel(torch.nn.Module):
     (scene/gaussian_model.py:36-44,108-131): parameters, activations, get_xyz / get_features, the deformation module."""
 
     def __init__(self, n, deform_cfg="dynerf_default", seed=6666, sh_degree=3, device="cpu", perturb_time_planes=0.1,
-                 deformation=None):
+                 deformation=None, scene="cube"):
         super().__init__()
         from . import deformation as D
-        g = make_gaussians(n, seed=seed, sh_degree=sh_degree)
+        g = make_gaussians(n, seed=seed, sh_degree=sh_degree, scene=scene)
         self._xyz = torch.nn.Parameter(g["xyz"])
         self._scaling = torch.nn.Parameter(g["scaling"])
         self._rotation = torch.nn.Parameter(g["rotation"])

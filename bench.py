@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--order", default="hilbert", choices=["hilbert", "morton", "random"],
                     help="order of the Gaussian set: hilbert = as fdgs.densify.spatial_reorder leaves it after every densification "
                          "(the order the train loop runs in), random = the generator's order")
+    ap.add_argument("--scene", default="cube", choices=["cube", "shell"],
+                    help="synthetic scene: cube = SURVEY 8d's generator (a volume that occludes itself: ~13 %% of the visible Gaussians get a "
+                         "gradient), shell = surface-like translucent scene (three thin spheres, opacity U(0.02, 0.2): ~98 %% do)")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of exactly --steps steps each; value = median; "
                     "0 = as many back-to-back regions as give >= 2 s of GPU work (at least 5, at most 80)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (forward-only, random order, all-tiles "
@@ -122,6 +125,27 @@ def timed_regions(step, first_step, steps, repeats, par, dev):
     return regions, local
 
 
+def multi_rank_report(par, rank, world, dev, local_regions, steps, rank_stats):
+    """The part of the JSON line that makes an N > 1 run self-verifying: which physical device every rank ran on (UUID / PCI bus id), every
+    rank's own median and p90 step time (before the closing barrier), what every rank rendered (`rank_stats`: e.g. num_rendered, visible), and
+    the blocking latency of the path's one collective.  Collective calls: every rank must call this."""
+    ms = sorted(x / steps * 1e3 for x in local_regions)
+    mine = {"rank": rank, "median_ms_per_step": round(ms[len(ms) // 2], 4), "p90_ms_per_step": round(_percentile(ms, 0.9), 4), **(rank_stats or {}),
+            "device": par.device_identity(dev)}
+    per_rank = par.gather_objects(mine)
+    ids = [r_["device"].get("uuid") or r_["device"].get("pci_bus_id") or (r_["device"]["device"], r_["device"]["pid"]) for r_ in per_rank]
+    return {"per_rank": per_rank, "distinct_devices": len(set(map(str, ids))), "allreduce_us_blocking": par.allreduce_latency_us(dev),
+            "rccl_note": None if world == 1 else "frame-parallel ranks met over torch.distributed (backend nccl = RCCL on GPUs)"}
+
+
+def rank0_leg(par, rank, fn):
+    """A leg only rank 0 runs (the CPU baseline and the oracle parity of the headline frame) -- for ANY world size: the other ranks wait at a
+    barrier, so that an N > 1 line carries cpu_baseline and parity too."""
+    out = fn() if rank == 0 else None
+    par.barrier()
+    return out
+
+
 def rank_plan(n_cams, steps, warmup, repeats, world):
     """Camera index every rank renders at every timed step (host logic of the frame-parallel split; tests/test_parallel.py)."""
     par = importlib.import_module("4dgaussians_amd.parallel")
@@ -145,7 +169,8 @@ def run(args, make_step=None):
         return _run_stub(args, make_step, par, rank, world, dev, ranks_seen)
     L = fdgs._lib.lib()
     N, W, H, dcfg = WORKLOADS[args.workload]
-    pc = syn.SynthModel(N, dcfg, seed=6666, device=dev)
+    scene = getattr(args, "scene", "cube")
+    pc = syn.SynthModel(N, dcfg, seed=6666, device=dev, scene=scene)
     if args.order != "random":
         fdgs.densify.spatial_reorder(pc, curve=args.order)
     pipe = syn.PipelineParams()
@@ -332,9 +357,36 @@ def run(args, make_step=None):
         extras["all_tiles_backward"] = {"frames_per_s": world * args.steps / dta, "ms_per_step": dta / args.steps * 1e3,
                                         "what": "FDGS_SKIP_DEAD=0: the deformation backward also walks the tiles whose gradient rows are all zero",
                                         "kernels_ms_per_step": {k: round(ka[k]["ms_per_step"], 4) for k in ("deform_bwd_data", "deform_wgrad", "deform_plane_grad") if k in ka}}
+        # ---- the OTHER scene statistic: a surface-like translucent scene in which nearly every visible Gaussian receives a gradient (no dead
+        # tiles to skip; long per-pixel walks) -- where a trained model without mass occlusion would land
+        other = "shell" if scene == "cube" else "cube"
+        pc_s = syn.SynthModel(N, dcfg, seed=6666, device=dev, scene=other)
+        if args.order != "random":
+            fdgs.densify.spatial_reorder(pc_s, curve=args.order)
+        step_s = make_render_step(pc_s)
+        for i in range(3):
+            step_s(i)
+        rg, _ = timed_regions(step_s, 3, args.steps, 3, par, dev)
+        ks = kernel_times(step_s, max(args.steps // 2, 2))
+        fdgs.deformation.COUNT_LIVE_TILES = True
+        step_s(args.warmup)
+        lt = fdgs.deformation.last_live_tiles
+        fdgs.deformation.COUNT_LIVE_TILES = False
+        dts = sorted(rg)[1]
+        n_live_s = lt[0] * 32
+        d2_flops = n_live_s * (sum(2 * Wd * Wd + 4 * Wd * k for k in ks_on) + 2 * Fd * Wd)
+        extras[other + "_scene"] = {"frames_per_s": world * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
+                                    "what": f"the same workload on synthetic scene {other!r} (bench.py --scene {other}): " +
+                                            ("three thin translucent spheres, opacity U(0.02, 0.2), half-size splats" if other == "shell" else "SURVEY 8d's cube"),
+                                    "num_rendered": int(fdgs.rasterizer.last_num_rendered),
+                                    "backward_live_tiles": {"live": lt[0], "tiles": lt[1], "frac": round(lt[0] / max(lt[1], 1), 4)},
+                                    "deform_bwd_data_frac_of_f32_mfma_peak": (d2_flops / (ks["deform_bwd_data"]["avg_ms"] * 1e-3) / MFMA_F32_PEAK) if "deform_bwd_data" in ks else None,
+                                    "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"])[:9]}}
+        del pc_s, step_s
+        torch.cuda.empty_cache()
         # ---- the generator's (random) order of the same scene: no spatial locality, no contiguous dead tiles
         if args.order != "random":
-            pc_r = syn.SynthModel(N, dcfg, seed=6666, device=dev)
+            pc_r = syn.SynthModel(N, dcfg, seed=6666, device=dev, scene=scene)
             step_r = make_render_step(pc_r)
             for i in range(3):
                 step_r(i)
@@ -414,17 +466,22 @@ def run(args, make_step=None):
         batched = {"views_per_step": B, "frames_per_s": world * B * nb / dt_b, "ms_per_step": dt_b / nb * 1e3, "ms_per_frame": dt_b / nb / B * 1e3,
                    "api": "fdgs.render_views (one autograd node and one gradient arena per optimizer step)"}
     cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cam_p = cams[args.warmup % len(cams)]
-        cpu, ref = cpu_baseline(fdgs, syn, pc, cam_p, target, dcfg, args.cpu_frames)
-        parity = parity_vs_oracle(fdgs, pc, cam_p, pipe, bg, params, ref)
+    if not args.no_cpu_baseline:
+        def cpu_leg():
+            cam_p = cams[args.warmup % len(cams)]
+            cpu_, ref = cpu_baseline(fdgs, syn, pc, cam_p, target, dcfg, args.cpu_frames)
+            return cpu_, parity_vs_oracle(fdgs, pc, cam_p, pipe, bg, params, ref)
+        leg = rank0_leg(par, rank, cpu_leg)        # rank 0, whatever the world size (the other ranks wait)
+        if leg is not None:
+            cpu, parity = leg
+    ranks = multi_rank_report(par, rank, world, dev, local_regions, args.steps, {"num_rendered": R, "visible": V})
 
     if rank == 0:
         out = {
             "metric": "train-step frames/sec (fwd+bwd raster+deform)", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "src_sha16": lib_sha16(fdgs),
-            "config": {"workload": args.workload, "gaussians": N, "image": [W, H], "deformation": dcfg,
+            "config": {"workload": args.workload, "scene": scene, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "gaussian_order": args.order, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V,
                        "backward_live_tiles": {"live": live_tiles, "tiles": all_tiles, "frac": round(live_frac, 4),
                                                "what": "32-Gaussian tiles with a non-zero gradient row (the others are culled / off-screen / "
@@ -434,10 +491,12 @@ def run(args, make_step=None):
             "timed_regions": len(regions), "timed_regions_ms_per_step": [round(x, 4) for x in ms_regions], "value_is": "median of the timed regions",
             **extras, "train_iteration": train, "batched_step": batched,
             "ranks_seen": ranks_seen, "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
-            "startup_s_per_rank": [round(x, 2) for x in per_rank_startup],
+            "startup_s_per_rank": [round(x, 2) for x in per_rank_startup], "ranks": ranks,
             "frame_hbm": {"algorithmic_bytes": B_frame, "achieved_GBps": B_frame / (dt / args.steps / 1) / 1e9 if world == 1 else None,
                           "frac_of_8TBps": (B_frame / (dt / args.steps)) / HBM_PEAK if world == 1 else None,
-                          "note": "working set < 256 MiB Infinity Cache at this size: the HBM fraction is structurally small"},
+                          "note": ("algorithmic bytes per frame < 256 MiB Infinity Cache at this size: the HBM fraction is structurally small"
+                                   if B_frame < (256 << 20) else
+                                   f"algorithmic bytes per frame {B_frame / 2**20:.0f} MiB > 256 MiB Infinity Cache: this workload streams HBM")},
             "mlp": {"fwd_bwd_flops_executed": sum(mfma_flops.values()), "fwd_bwd_flops_all_tiles": 3 * flops_fwd,
                     "achieved_TFLOPs_in_mfma_kernels": (sum(mfma_flops.values()) / (sum(kern[k]["ms_per_step"] for k in mfma_flops if k in kern) * 1e-3) / 1e12)
                     if kern else None, "peak_TFLOPs": MFMA_F32_PEAK / 1e12},
@@ -474,7 +533,10 @@ def _run_stub(args, make_step, par, rank, world, dev, ranks_seen):
     per_rank_ms = [x / args.steps * 1e3 for x in par.gather_floats(sorted(local)[len(local) // 2], dev)]
     per_rank_startup = par.gather_floats(startup_s, dev)
     cams_all = par.gather_floats(float(sum(seen[args.warmup:])), dev)
-    out = {"metric": "stub", "value": world * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    cpu_leg = getattr(step_fn, "cpu_leg", None)          # (tests: stands in for cpu_baseline + parity_vs_oracle; rank 0 only, any world size)
+    leg = rank0_leg(par, rank, cpu_leg) if cpu_leg is not None else None
+    ranks = multi_rank_report(par, rank, world, dev, local, args.steps, {"num_rendered": 1000 + rank})
+    out = {"metric": "stub", "cpu_baseline": None if leg is None else leg[0], "parity": None if leg is None else leg[1], "ranks": ranks, "value": world * args.steps / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
            "startup_s_per_rank": per_rank_startup, "timed_regions": len(regions), "camera_index_sums": cams_all,
            "cameras_rank_local": seen[args.warmup:]}

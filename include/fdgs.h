@@ -76,6 +76,8 @@ typedef struct fdgs_raster_params {
     const float* scales;    /* opt [P,3] (scales+rotations xor cov3D_precomp) */
     const float* rotations; /* opt [P,4] (w,x,y,z), used as given (no normalisation) */
     const float* cov3D_precomp; /* opt [P,6] */
+    uint8_t* visibility;    /* opt [P], written by fdgs_preprocess_fwd: 1 where radii > 0 (the `visibility_filter` render() returns,
+                               gaussian_renderer/__init__.py:136) -- saves the caller one elementwise launch per frame */
 } fdgs_raster_params;
 
 /* Stage 1: per-Gaussian projection (frustum cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB).
@@ -123,6 +125,9 @@ typedef struct fdgs_raster_deform_epilogue {
                                     MUST hand G to fdgs_deform_bwd with packed_rows_ready = 3, which never reads them (the one dead tile it
                                     may use as padding is zero-filled there).
                                     0: no flags (packed_rows_ready = 1: fdgs_deform_bwd walks every tile) */
+    float* zero_fill;            /* opt: a float range this kernel zero-fills on the way (16-byte aligned; zero_floats a multiple of 4): the part
+                                    of the caller's gradient arena that fdgs_deform_bwd ACCUMULATES into (planes, MLP) -- saves a fill launch */
+    size_t zero_floats;
 } fdgs_raster_deform_epilogue;
 
 typedef struct fdgs_raster_grads {

@@ -304,6 +304,7 @@ def _bench_stub_rank(path, steps, warmup, repeats):
     def make_step(ctx):
         def step(i, cam):
             time.sleep(0.002 * (1 + 2 * ctx["rank"]))       # rank 1 is three times slower: MAX over ranks must report it
+        step.cpu_leg = lambda: ({"value": 0.3, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "stub"}, {"image_psnr_dB": 100.0, "grad_ok": True})
         return step
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -335,6 +336,13 @@ def test_bench_rank_logic_with_a_stub_step(tmp_path):
         if r == 0:
             line = json.loads(printed.strip())                            # exactly one JSON line, on rank 0 only
             assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warmup
+            # an N > 1 line verifies itself: CPU baseline + oracle parity (rank 0's leg, any world size), who ran where, what each rank did
+            assert line["cpu_baseline"]["value"] == 0.3 and line["parity"]["grad_ok"] is True
+            rk = line["ranks"]
+            assert [x["rank"] for x in rk["per_rank"]] == [0, 1] and rk["distinct_devices"] == 2 and rk["allreduce_us_blocking"] > 0
+            assert [x["num_rendered"] for x in rk["per_rank"]] == [1000, 1001]
+            assert all(x["p90_ms_per_step"] >= x["median_ms_per_step"] > 0 and "device" in x for x in rk["per_rank"])
+            assert rk["per_rank"][1]["median_ms_per_step"] > 2.0 * rk["per_rank"][0]["median_ms_per_step"]
         else:
             assert printed.strip() == ""
     assert res[0][0]["ms_per_step"] == res[1][0]["ms_per_step"]
