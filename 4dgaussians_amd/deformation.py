@@ -32,6 +32,11 @@ HEAD_K = (3, 3, 4, 1, 48)
 PLANE_PAIRS = list(itertools.combinations(range(4), 2))
 
 
+def _is_hip_device(dev):
+    """(one predicate so that the host dry-run test can stand in for a device; there is no CPU path)"""
+    return dev.type == "cuda"
+
+
 class HexPlaneField(nn.Module):
     def __init__(self, bounds, planeconfig, multires):
         super().__init__()
@@ -328,7 +333,7 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
     then also leaves the activations behind (SAVE_ACTIVATIONS)."""
     L = _lib.lib()
     dev = xyz.device
-    if dev.type != "cuda":
+    if not _is_hip_device(dev):
         raise _lib.FdgsError("the deformation kernels run on the GPU only")
     nplanes = cfg["L"] * 6
     planes_in, mlp_in = rest[:nplanes], rest[nplanes:]
@@ -363,7 +368,7 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
 
 
 class _BwdBuffers:
-    __slots__ = ("g", "arena", "d_xyz", "d_sc", "d_rot", "d_op", "d_sha", "d_shb", "d_planes", "d_mlp", "scratch", "keep")
+    __slots__ = ("g", "arena", "d_xyz", "d_sc", "d_rot", "d_op", "d_sha", "d_shb", "d_planes", "d_mlp", "scratch", "keep", "zero_range")
 
 
 def backward_prepare(st, o_sc, o_rot, o_op, identity_assigned=False, zero_by_epilogue=False):

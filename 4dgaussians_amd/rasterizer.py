@@ -22,6 +22,11 @@ from . import _lib
 from ._lib import RasterGrads, RasterParams, check, ptr, stream_ptr
 
 
+def _is_hip_device(dev):
+    """(one predicate so that the host dry-run test can stand in for a device; there is no CPU path)"""
+    return dev.type == "cuda"
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -72,7 +77,7 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     buffers to write into (contiguous float32 / int32 on the device), e.g. slices of a batch tensor."""
     L = _lib.lib()
     dev = means3D.device
-    if dev.type != "cuda":
+    if not _is_hip_device(dev):
         raise _lib.FdgsError("the rasterizer runs on the GPU only (tensors must live on a HIP device)")
     means3D = _f32(means3D, dev)
     P = means3D.shape[0]
