@@ -47,7 +47,7 @@ class DeformParams(Structure):
 
 class DeformOut(Structure):
     _fields_ = [("xyz", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("opacity", c_void_p), ("shs", c_void_p),
-                ("rot_norm", c_void_p), ("saved", c_void_p)]
+                ("rot_norm", c_void_p), ("saved", c_void_p), ("packed", c_void_p)]
 
 
 class DeformGrads(Structure):
@@ -105,6 +105,7 @@ SYMBOLS = {
     "fdgs_binning_field": (c_int, [c_void_p, c_uint32, c_int, c_int, c_int, POINTER(c_void_p)]),
     "fdgs_img_field": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "fdgs_deform_saved_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
+    "fdgs_deform_pack_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_fwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformOut)]),
     "fdgs_deform_bwd_scratch_bytes": (c_int, [POINTER(DeformParams), POINTER(c_size_t)]),
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),

@@ -115,6 +115,8 @@ struct DeformDev {
     uint32_t* sv_hmask;             // [Npad/32][64 lanes][4]: bit r of word t = relu(hidden) tile t register r > 0 (what D2's lane needs)
     int Npad;
     int head_slot[FDGS_NUM_HEADS];
+    const float* packed;            // form 16: W0 / W1 as operand streams (pack_weights16_kernel)
+    int skew;                       // form 16: start delay (s_memtime ticks) of the second half of the grid (FDGS_D16_SKEW)
 };
 
 // 4 consecutive features f0..f0+3 (all inside one level because C % 8 == 0) of one Gaussian.
@@ -272,9 +274,23 @@ struct DenseIL {
             bp[ot] = bias + row;
         }
     }
+    // Packed operand stream (pack_weights32_kernel, round 4): the matrix re-ordered so that step s, output tile ot is ONE contiguous run of
+    // 64 lanes x KT floats -- a request touches 8 cache lines instead of 64 (row-major, every lane's KT floats sit in their own 128-byte line:
+    // at one line per clock and CU the four waves' operand requests kept the texture path busy for as long as their MFMAs ran).
+    int step_stride = 0;     // 0: row-major addressing (rho walk); else floats between consecutive steps of the packed stream
+    __device__ __forceinline__ void setup_packed(const float* __restrict__ P, const float* __restrict__ bias, int out_dim, int g, int h, int lane) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) {
+            int row = ROW_IL ? OT * g + ot : 32 * ot + g;
+            if (CLAMP) row = row < out_dim ? row : out_dim - 1;
+            rp[ot] = P + (size_t)(ot * 64 + lane) * KT;
+            bp[ot] = bias + row;
+        }
+        step_stride = OT * 64 * KT;
+    }
     __device__ __forceinline__ void fetch(int s, AVec<KT>* dst) const {
 #pragma unroll
-        for (int ot = 0; ot < OT; ot++) dst[ot] = ldv<KT>(rp[ot] + KT * rho(s, 0));
+        for (int ot = 0; ot < OT; ot++) dst[ot] = ldv<KT>(rp[ot] + (step_stride ? s * step_stride : KT * rho(s, 0)));
     }
     __device__ __forceinline__ void preload() {
 #pragma unroll
@@ -562,7 +578,13 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     T0.preload();
     int hd = next_head_m(head_mask, -1);
     DenseIL<WT, WT, true, PD1, false> L1;
-    if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const float* pk = d.packed ? d.packed + (size_t)d.F * W : nullptr;      // the heads' W1 as operand streams (fdgs_deform_out::packed)
+    if (hd < FDGS_NUM_HEADS) {
+        if (pk) L1.setup_packed(pk + (size_t)hd * W * W, p.b1[hd], W, g, h, lane_o); else L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);
+        L1.preload();
+    }
     float q[4], xyz[3];
     load_query(p, d.sc, n, q, xyz);
     // every per-Gaussian input of the epilogues is fetched now (one HBM round trip under the gather) instead of once per
@@ -690,7 +712,10 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
         if (k > 32) { L2b.setup(w2h + 32 * LDW, p.b2[hd] + 32, LDW, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head_m(head_mask, hd);
-        if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
+        if (nxt < FDGS_NUM_HEADS) {
+            if (pk) L1.setup_packed(pk + (size_t)nxt * W * W, p.b1[nxt], W, g, h, lane_o); else L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h);
+            L1.preload();
+        }
         f32x16 o0 = zero16(), o1 = zero16();
         D1_TICK(4);
         if (small) {
@@ -716,6 +741,23 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         atomicAdd(&d.prof[8], 1ull);
     }
 #endif
+}
+
+#include "deform_fwd16.h"
+
+// The heads' W1 as the operand streams of the 32-Gaussian forward kernel's DenseIL walk: vector (KT floats) index (s * OT + ot) * 64 + lane
+// = W1[OT g + ot][KT rho(s, 0) + KT 4 h .. + KT - 1], lane = (g, h).  Same buffer layout as the 16-form's ([W0 slot][head 0] ... [head 4]).
+__global__ void __launch_bounds__(256) pack_weights32_kernel(PackArgs a) {
+    const int W = a.W, T = W / 32;
+    const int nv_head = W * W / T;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= FDGS_NUM_HEADS * nv_head) return;
+    const int hd = e / nv_head, k = e - hd * nv_head;
+    if (!a.head_on[hd]) return;
+    const int lane = k & 63, ot = (k >> 6) % T, s = k / (64 * T), g = lane & 31, h = lane >> 5;
+    const float* src = a.w1[hd] + (size_t)(T * g + ot) * W + T * rho(s, 0) + T * 4 * h;
+    float* dst = a.out + (size_t)a.F * W + (size_t)hd * W * W + (size_t)k * T;
+    for (int i = 0; i < T; i++) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------ backward: prep
@@ -2302,6 +2344,12 @@ struct FwdLauncher {
         hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
+template <int WT, int FCH>
+struct Fwd16Launcher {
+    static void go(hipStream_t s, int blocks, const DeformDev& d) {
+        if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2>), dim3(blocks), dim3(256), 0, s, d);
+    }
+};
 template <int WT, int FCH, bool SAVED>
 static void launch_bwd_data(hipStream_t s, int max_blocks, const BwdDev& d) {
     // persistent: as many workgroups as are co-resident (each keeps dW2/db2 sums in LDS), tiles handed out round-robin
@@ -2385,8 +2433,31 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         d.ntiles = 4 * cdiv(p->N, 128);
         static int cus = 0;
         if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
-        const int want = tunable("FDGS_D1_WGS", cus);     // 0: one workgroup per four tiles (not persistent)
-        const int wgs = want > 0 && want < d.ntiles / 4 ? want : d.ntiles / 4;
+        // 16-Gaussian form (deform_fwd16.h): two workgroups per CU, needs whole float4 texel quarters per lane group (C % 16 == 0)
+        const bool form16 = tunable("FDGS_D1_FORM", 32) == 16 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
+        d.packed = reinterpret_cast<const float*>(out->packed);
+        d.skew = tunable("FDGS_D16_SKEW", 600);
+        if (!form16 && out->packed && tunable("FDGS_D1_PACK32", 0)) {
+            FDGS_TIMED("pack_weights", stream);
+            PackArgs pa{};
+            pa.W = p->W; pa.F = d.F; pa.out = reinterpret_cast<float*>(out->packed);
+            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
+            const int nv = FDGS_NUM_HEADS * p->W * p->W / (p->W / 32);
+            hipLaunchKernelGGL(pack_weights32_kernel, dim3(cdiv(nv, 256)), dim3(256), 0, stream, pa);
+        } else if (!form16) {
+            d.packed = nullptr;
+        }
+        if (form16) {
+            FDGS_TIMED("pack_weights", stream);
+            PackArgs pa{};
+            pa.w0 = p->w0; pa.W = p->W; pa.F = d.F; pa.out = reinterpret_cast<float*>(out->packed);
+            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
+            const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4;
+            hipLaunchKernelGGL(pack_weights16_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, pa);
+        }
+        const int want = tunable("FDGS_D1_WGS", form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
+        const int wg_tiles = form16 ? d.ntiles / 2 : d.ntiles / 4;           // (form 16: four 16-Gaussian tiles per workgroup)
+        const int wgs = want > 0 && want < wg_tiles ? want : wg_tiles;
         d.prof = nullptr;
 #ifdef FDGS_PROFILE_D1
         static unsigned long long* prof_dev = nullptr;
@@ -2394,7 +2465,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
         d.prof = prof_dev;
 #endif
-        rc = dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+        rc = form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
 #ifdef FDGS_PROFILE_D1
         {
             static int reports = 0;
@@ -2414,6 +2485,14 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     }
     if (rc) return rc;
     FDGS_LAUNCH_CHECK("deform_fwd", 0, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_deform_pack_bytes(const fdgs_deform_params* p, size_t* bytes) {
+    int rc = validate_deform(p);
+    if (rc) return rc;
+    FDGS_REQUIRE(bytes, "bytes is NULL");
+    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W) * sizeof(float);
     return FDGS_OK;
 }
 

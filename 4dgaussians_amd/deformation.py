@@ -328,6 +328,9 @@ class _FwdState:
     __slots__ = ("cfg", "p", "keep", "saved_act", "o_xyz", "o_sc", "o_rot", "o_op", "o_sh", "o_norm", "shapes", "plane_shapes")
 
 
+_pack_scratch = {}
+
+
 def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, rest, want_backward):
     """Runs fdgs_deform_fwd.  `want_backward`: a backward will follow (grad mode on and some input requires grad): the forward
     then also leaves the activations behind (SAVE_ACTIVATIONS)."""
@@ -360,6 +363,17 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
         saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     out.saved = ptr(saved)
     st.saved_act = saved
+    # scratch for the operand-stream copy of W0 / W1 the 16-Gaussian form of the forward kernel reads (re-packed by every forward: the
+    # weights change every optimizer step); one persistent buffer per (device, size): forwards on a stream are ordered
+    nbytes = _lib.c_size_t()
+    check(L.fdgs_deform_pack_bytes(p, nbytes))
+    key = (dev, nbytes.value)
+    packed = _pack_scratch.get(key)
+    if packed is None:
+        if len(_pack_scratch) > 8:
+            _pack_scratch.clear()
+        packed = _pack_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out.packed = ptr(packed)
     check(L.fdgs_deform_fwd(stream_ptr(), p, out))
     st.cfg, st.p = cfg, p
     st.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape, sh_b=None if sh_b is None else sh_b.shape)

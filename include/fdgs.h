@@ -217,9 +217,14 @@ typedef struct fdgs_deform_out {
     void* saved;      /* opt, fdgs_deform_saved_bytes() bytes: when given, the forward also stores the HexPlane features,
                          relu(hidden) and relu(h1) of every active head; handing the same buffer to fdgs_deform_bwd lets the
                          backward skip the gather and the recomputation of those layers (about 40 % of its MFMA work) */
+    void* packed;     /* opt, fdgs_deform_pack_bytes() bytes of scratch: when given (and C % 16 == 0), the forward first re-orders W0 and the
+                         heads' W1 into it as the operand streams of its matrix-core loops (contiguous 1-KB loads instead of 64 cache lines
+                         per request) and runs its 16-Gaussians-per-wave form, two waves per SIMD; NULL: the 32-Gaussian form on the
+                         row-major weights.  Same results up to summation order, same `saved` format. */
 } fdgs_deform_out;
 
 int fdgs_deform_saved_bytes(const fdgs_deform_params* p, size_t* bytes);
+int fdgs_deform_pack_bytes(const fdgs_deform_params* p, size_t* bytes);
 int fdgs_deform_fwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_out* out);
 
 typedef struct fdgs_deform_grads {

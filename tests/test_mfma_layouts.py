@@ -31,3 +31,18 @@ def test_mfma_models_match_definition():
                 assert np.isclose(d[j + 32 * hh, r], a[i] * b[j] + a[i + 32] * b[j + 32])
     d4 = model.mfma4(a, b, np.zeros((64, 4)))
     assert np.isclose(d4[4 * 5 + 2, 3], a[4 * 5 + 3] * b[4 * 5 + 2])
+
+
+@pytest.mark.parametrize("W,F,k", [(128, 32, 3), (128, 32, 48), (64, 64, 4), (128, 48, 1), (64, 32, 48), (128, 96, 4)])
+def test_16_gaussian_forms_consistent(W, F, k):
+    """The v_mfma_f32_16x16x4_f32 forms of the forward kernel (csrc/deform_fwd16.h): one wave = 16 Gaussians."""
+    assert model.check16(W, F, k, np.random.default_rng(W + F + k))
+
+
+def test_mfma16_model_matches_definition():
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal(64), rng.standard_normal(64)
+    d = model.mfma16(a, b, np.zeros((64, 4)))
+    for (n, q, r) in ((0, 0, 0), (5, 2, 3), (15, 3, 1)):
+        row = 4 * q + r
+        assert np.isclose(d[n + 16 * q, r], sum(a[row + 16 * kk] * b[n + 16 * kk] for kk in range(4)))

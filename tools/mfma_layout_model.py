@@ -210,7 +210,132 @@ def check(WT, FCH, k, rng):
     return True
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The 16-Gaussian forms of the forward kernel (csrc/deform_fwd16.h): one wave = 16 Gaussians on v_mfma_f32_16x16x4_f32
+# (A[i][k] in lane i+16k, B[k][n] in lane n+16k, D[row][n] in lane n+16q register r with row = 4q + r).  Lane = (n, q).
+# "IL16" activation layout with T = W/16 tiles: tile t, register r of lane (n, q) holds feature T*(4q+r) + t of Gaussian n.
+N16 = LANES & 15
+Q16 = LANES >> 4
+
+
+def mfma16(a, b, c):
+    """a, b: [64]; c: [64,4] -> new c."""
+    A = a.reshape(4, 16).T          # A[i][k]
+    B = b.reshape(4, 16)            # B[k][n]
+    D = A @ B                       # [16 rows][16 n]
+    out = c.copy()
+    for r in range(4):
+        for q in range(4):
+            out[16 * q:16 * q + 16, r] += D[4 * q + r, :]
+    return out
+
+
+def matrix_to_il16(M, T):
+    return [np.stack([M[N16, T * (4 * Q16 + r) + t] for r in range(4)], 1) for t in range(T)]
+
+
+def il16_to_matrix(X, T):
+    M = np.zeros((16, 16 * T))
+    for t in range(T):
+        for r in range(4):
+            for lane in range(64):
+                M[lane & 15, T * (4 * (lane >> 4) + r) + t] = X[t][lane, r]
+    return M
+
+
+def feat16(Fm):
+    """[16, F] -> per 16-feature group u: registers c<4 of lane (n,q) hold features 16u + 4q + c."""
+    return [np.stack([Fm[N16, 16 * u + 4 * Q16 + c] for c in range(4)], 1) for u in range(Fm.shape[1] // 16)]
+
+
+def trunk16(W0, b0, feat, OT):
+    Y = []
+    for ot in range(OT):
+        Y.append(mfma16(np.where(Q16 == 0, b0[OT * N16 + ot], 0.0), np.ones(64), np.zeros((64, 4))))
+    for u in range(len(feat)):
+        for c in range(4):
+            for ot in range(OT):
+                Y[ot] = mfma16(W0[OT * N16 + ot, 16 * u + 4 * Q16 + c], feat[u][:, c], Y[ot])
+    return Y
+
+
+def dense_il16(Wm, bias, X, KT, OT):
+    Y = [mfma16(np.where(Q16 == 0, bias[OT * N16 + ot], 0.0), np.ones(64), np.zeros((64, 4))) for ot in range(OT)]
+    for r in range(4):
+        for t in range(KT):
+            for ot in range(OT):
+                Y[ot] = mfma16(Wm[OT * N16 + ot, KT * (4 * Q16 + r) + t], X[t][:, r], Y[ot])
+    return Y
+
+
+def small_head16(W2, b2, k, X, KT):
+    acc = np.zeros((64, 4))
+    row = np.minimum(LANES & 3, k - 1)
+    for r in range(4):
+        for t in range(KT):
+            acc = mfma4(W2[row, KT * (4 * Q16 + r) + t], X[t][:, r], acc)
+    x = acc + acc[LANES ^ 16]
+    x = x + x[LANES ^ 32]
+    return x + b2[np.minimum(np.arange(4), k - 1)][None, :]
+
+
+def tall_head16(W2, b2, k, X, KT):
+    """k = 16 * NT output rows in standard order: returns [16, k]."""
+    NT = (k + 15) // 16
+    out = np.zeros((16, 16 * NT))
+    for ot in range(NT):
+        rows = np.minimum(16 * ot + N16, k - 1)
+        Y = mfma16(np.where(Q16 == 0, b2[rows], 0.0), np.ones(64), np.zeros((64, 4)))
+        for r in range(4):
+            for t in range(KT):
+                Y = mfma16(W2[rows, KT * (4 * Q16 + r) + t], X[t][:, r], Y)
+        for r in range(4):
+            for lane in range(64):
+                out[lane & 15, 16 * ot + 4 * (lane >> 4) + r] = Y[lane, r]
+    return out[:, :k]
+
+
+def hmask_words_from_rows(rh_rows, W):
+    """What D2 reads (sv_hmask): for the 32-Gaussian tile with relu(hidden) rows `rh_rows` [32, W]: lane (g, h) word t bit r =
+    rh[g, T32 * rho(r, h) + t] > 0 with T32 = W / 32."""
+    T32 = W // 32
+    words = np.zeros((64, 4), np.uint32)
+    for lane in range(64):
+        g, h = lane & 31, lane >> 5
+        for t in range(T32):
+            for r in range(16):
+                if rh_rows[g, T32 * rho(r, h) + t] > 0:
+                    words[lane, t] |= np.uint32(1 << r)
+    return words
+
+
+def check16(W, F, k, rng):
+    T = W // 16
+    feat = rng.standard_normal((16, F))
+    W0, b0 = rng.standard_normal((W, F)), rng.standard_normal(W)
+    W1, b1 = rng.standard_normal((W, W)), rng.standard_normal(W)
+    W2, b2 = rng.standard_normal((k, W)), rng.standard_normal(k)
+    hid_ref = np.maximum(feat @ W0.T + b0, 0)
+    h1_ref = np.maximum(hid_ref @ W1.T + b1, 0)
+    out_ref = h1_ref @ W2.T + b2
+    hid = [np.maximum(x, 0) for x in trunk16(W0, b0, feat16(feat), T)]
+    assert np.allclose(il16_to_matrix(hid, T), hid_ref), "trunk16"
+    assert np.allclose(il16_to_matrix(matrix_to_il16(hid_ref, T), T), hid_ref)
+    h1 = [np.maximum(x, 0) for x in dense_il16(W1, b1, hid, T, T)]
+    assert np.allclose(il16_to_matrix(h1, T), h1_ref), "L1 16"
+    if k <= 4:
+        o4 = small_head16(W2, b2, k, h1, T)
+        for q in range(4):
+            assert np.allclose(o4[16 * q:16 * q + 16, :k], out_ref), "small head 16"
+    else:
+        assert np.allclose(tall_head16(W2, b2, k, h1, T), out_ref), "tall head 16"
+    return True
+
+
 if __name__ == "__main__":
+    for W, F, k in [(128, 32, 3), (128, 32, 48), (64, 64, 4), (128, 48, 1), (64, 32, 48)]:
+        check16(W, F, k, np.random.default_rng(1))
+        print(f"16-Gaussian forms W={W} F={F} k={k}: layouts consistent")
     rng = np.random.default_rng(0)
     for WT, FCH, k in [(4, 4, 3), (4, 4, 48), (4, 6, 4), (2, 8, 1), (2, 16, 48), (4, 12, 3)]:
         check(WT, FCH, k, rng)
