@@ -36,8 +36,12 @@ void timing_end(void* rec, hipStream_t stream) {
 }
 
 // [sum |a-b|, sum (a-b)^2, n] with optional dL/da = sign(a-b)*scale (utils/loss_utils.py:20-21 of the reference)
-__global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, size_t n4, const float* __restrict__ a, const float* __restrict__ b,
-                                                       float scale, float* __restrict__ grad, float* __restrict__ acc) {
+// One 1024-thread workgroup per CU, two float4 pairs in flight per thread (64 KB of requests per CU), ONE pair of atomics per workgroup:
+// same-address float atomics retire at ~80 M/s on MI355X, so the 1 024 of the 512 x 256-thread form of rounds 1-3 were more
+// than half of its 22 us.
+constexpr int L1S_THREADS = 1024;
+__global__ void __launch_bounds__(L1S_THREADS) l1_stats_kernel(size_t n, size_t n4, const float* __restrict__ a, const float* __restrict__ b,
+                                                               float scale, float* __restrict__ grad, float* __restrict__ acc) {
     float s1 = 0.f, s2 = 0.f;
     // n4 = number of 16-byte groups handled with float4 accesses (0 when a pointer is not 16-byte aligned), scalar tail
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -48,23 +52,33 @@ __global__ void __launch_bounds__(256) l1_stats_kernel(size_t n, size_t n4, cons
         s1 += fabsf(d); s2 += d * d;
         return d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
     };
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t stride = (size_t)gridDim.x * L1S_THREADS;
+    size_t i = (size_t)blockIdx.x * L1S_THREADS + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const float4 x0 = a4[i], y0 = b4[i], x1 = a4[i + stride], y1 = b4[i + stride];
+        const float4 g0 = make_float4(one(x0.x, y0.x), one(x0.y, y0.y), one(x0.z, y0.z), one(x0.w, y0.w));
+        const float4 g1 = make_float4(one(x1.x, y1.x), one(x1.y, y1.y), one(x1.z, y1.z), one(x1.w, y1.w));
+        if (grad) { g4[i] = g0; g4[i + stride] = g1; }
+    }
+    for (; i < n4; i += stride) {
         const float4 x = a4[i], y = b4[i];
         const float4 g = make_float4(one(x.x, y.x), one(x.y, y.y), one(x.z, y.z), one(x.w, y.w));
         if (grad) g4[i] = g;
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float g = one(a[i], b[i]);
-        if (grad) grad[i] = g;
+    for (size_t k = n4 * 4 + (size_t)blockIdx.x * L1S_THREADS + threadIdx.x; k < n; k += stride) {
+        const float g = one(a[k], b[k]);
+        if (grad) grad[k] = g;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    __shared__ float w1[4], w2[4];
+    __shared__ float w1[L1S_THREADS / 64], w2[L1S_THREADS / 64];
     if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[0], w1[0] + w1[1] + w1[2] + w1[3]);
-        atomicAdd(&acc[1], w2[0] + w2[1] + w2[2] + w2[3]);
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < L1S_THREADS / 64; k++) { t1 += w1[k]; t2 += w2[k]; }
+        atomicAdd(&acc[0], t1);
+        atomicAdd(&acc[1], t2);
         if (blockIdx.x == 0) atomicAdd(&acc[2], (float)n);
     }
 }
@@ -122,10 +136,10 @@ extern "C" int fdgs_l1_stats(void* stream_, size_t n, const float* a, const floa
     hipStream_t stream = (hipStream_t)stream_;
     const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_out_opt) & 15) == 0;
     const size_t n4 = aligned ? n / 4 : 0;
-    int blocks = (int)(((aligned ? n / 4 : n) + 255) / 256);
+    int blocks = (int)(((aligned ? n / 4 : n) + L1S_THREADS - 1) / L1S_THREADS);
     if (blocks < 1) blocks = 1;
-    if (blocks > 512) blocks = 512;   // two atomics per workgroup on the same two words: keep the tail short
-    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(256), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc); }
+    if (blocks > 256) blocks = 256;   // one workgroup per CU; two atomics per workgroup on the same two words
+    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(L1S_THREADS), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc); }
     FDGS_LAUNCH_CHECK("l1_stats", 0, stream);
     return FDGS_OK;
 }

@@ -501,6 +501,9 @@ __device__ __forceinline__ int next_head_m(unsigned mask, int hd) {
 #ifndef FDGS_D1_PD1
 #define FDGS_D1_PD1 2
 #endif
+#ifndef FDGS_D1_DRAIN_PIPE
+#define FDGS_D1_DRAIN_PIPE 0      // (1: drain software-pipelined by one piece -- measured no faster, profiles/r04_d1_forms.txt)
+#endif
 template <int WT>
 struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
 
@@ -627,10 +630,28 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         store_il<WT>(my_tile + g * TSTRIDE, x, h);
         pending_dst = dst;
     };
+    // software-pipelined by one piece (round 4): hook j issues the LDS read of piece j and stores piece j - 1, so that no hook waits for
+    // its own read (s_waitcnt lgkmcnt(0) right in front of a step's MFMAs: ~50 idle cycles per step)
+    float4 drain_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    int drain_held = -1;                // piece sitting in drain_reg (compile-time after unrolling)
+    auto drain_flush = [&]() {
+        if (FDGS_D1_DRAIN_PIPE && pending_dst && drain_held >= 0) reinterpret_cast<float4*>(pending_dst)[drain_held * 64 + lane] = drain_reg;
+        drain_held = -1;
+    };
     auto drain_piece = [&](int j) {     // pieces j = 0 .. 4*WT-1 of 64 float4 each
-        if (pending_dst && j < WT * 4) {
-            const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
-            reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
+        if (pending_dst) {
+            if (FDGS_D1_DRAIN_PIPE) {
+                if (drain_held >= 0) reinterpret_cast<float4*>(pending_dst)[drain_held * 64 + lane] = drain_reg;
+                drain_held = -1;
+                if (j < WT * 4) {
+                    const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
+                    drain_reg = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
+                    drain_held = j;
+                }
+            } else if (j < WT * 4) {
+                const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
+                reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
+            }
         }
     };
     if (d.sv_rh && primary) park(hid, d.sv_rh + tile_n0 * W);
@@ -707,6 +728,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         L2.preload();
         f32x16 h1[WT];
         L1.run(hid, h1, h, drain_piece);
+        drain_flush();
         D1_TICK(3);
         relu_inplace<WT>(h1);
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
@@ -733,6 +755,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     // the last parked tile has no following layer to hide under
 #pragma unroll
     for (int j = 0; j < WT * 4; j++) drain_piece(j);
+    drain_flush();
     D1_TICK(7);
     }   // tile loop
 #ifdef FDGS_PROFILE_D1
