@@ -274,23 +274,9 @@ struct DenseIL {
             bp[ot] = bias + row;
         }
     }
-    // Packed operand stream (pack_weights32_kernel, round 4): the matrix re-ordered so that step s, output tile ot is ONE contiguous run of
-    // 64 lanes x KT floats -- a request touches 8 cache lines instead of 64 (row-major, every lane's KT floats sit in their own 128-byte line:
-    // at one line per clock and CU the four waves' operand requests kept the texture path busy for as long as their MFMAs ran).
-    int step_stride = 0;     // 0: row-major addressing (rho walk); else floats between consecutive steps of the packed stream
-    __device__ __forceinline__ void setup_packed(const float* __restrict__ P, const float* __restrict__ bias, int out_dim, int g, int h, int lane) {
-#pragma unroll
-        for (int ot = 0; ot < OT; ot++) {
-            int row = ROW_IL ? OT * g + ot : 32 * ot + g;
-            if (CLAMP) row = row < out_dim ? row : out_dim - 1;
-            rp[ot] = P + (size_t)(ot * 64 + lane) * KT;
-            bp[ot] = bias + row;
-        }
-        step_stride = OT * 64 * KT;
-    }
     __device__ __forceinline__ void fetch(int s, AVec<KT>* dst) const {
 #pragma unroll
-        for (int ot = 0; ot < OT; ot++) dst[ot] = ldv<KT>(rp[ot] + (step_stride ? s * step_stride : KT * rho(s, 0)));
+        for (int ot = 0; ot < OT; ot++) dst[ot] = ldv<KT>(rp[ot] + KT * rho(s, 0));
     }
     __device__ __forceinline__ void preload() {
 #pragma unroll
@@ -501,9 +487,6 @@ __device__ __forceinline__ int next_head_m(unsigned mask, int hd) {
 #ifndef FDGS_D1_PD1
 #define FDGS_D1_PD1 2
 #endif
-#ifndef FDGS_D1_DRAIN_PIPE
-#define FDGS_D1_DRAIN_PIPE 0      // (1: drain software-pipelined by one piece -- measured no faster, profiles/r04_d1_forms.txt)
-#endif
 template <int WT>
 struct FwdPD { static constexpr int L1 = WT == 4 ? 2 : 4, L2 = 8; };
 
@@ -581,13 +564,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     T0.preload();
     int hd = next_head_m(head_mask, -1);
     DenseIL<WT, WT, true, PD1, false> L1;
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
-    const float* pk = d.packed ? d.packed + (size_t)d.F * W : nullptr;      // the heads' W1 as operand streams (fdgs_deform_out::packed)
-    if (hd < FDGS_NUM_HEADS) {
-        if (pk) L1.setup_packed(pk + (size_t)hd * W * W, p.b1[hd], W, g, h, lane_o); else L1.setup(p.w1[hd], p.b1[hd], W, W, g, h);
-        L1.preload();
-    }
+    if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
     float q[4], xyz[3];
     load_query(p, d.sc, n, q, xyz);
     // every per-Gaussian input of the epilogues is fetched now (one HBM round trip under the gather) instead of once per
@@ -630,28 +607,10 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         store_il<WT>(my_tile + g * TSTRIDE, x, h);
         pending_dst = dst;
     };
-    // software-pipelined by one piece (round 4): hook j issues the LDS read of piece j and stores piece j - 1, so that no hook waits for
-    // its own read (s_waitcnt lgkmcnt(0) right in front of a step's MFMAs: ~50 idle cycles per step)
-    float4 drain_reg = make_float4(0.f, 0.f, 0.f, 0.f);
-    int drain_held = -1;                // piece sitting in drain_reg (compile-time after unrolling)
-    auto drain_flush = [&]() {
-        if (FDGS_D1_DRAIN_PIPE && pending_dst && drain_held >= 0) reinterpret_cast<float4*>(pending_dst)[drain_held * 64 + lane] = drain_reg;
-        drain_held = -1;
-    };
     auto drain_piece = [&](int j) {     // pieces j = 0 .. 4*WT-1 of 64 float4 each
-        if (pending_dst) {
-            if (FDGS_D1_DRAIN_PIPE) {
-                if (drain_held >= 0) reinterpret_cast<float4*>(pending_dst)[drain_held * 64 + lane] = drain_reg;
-                drain_held = -1;
-                if (j < WT * 4) {
-                    const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
-                    drain_reg = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
-                    drain_held = j;
-                }
-            } else if (j < WT * 4) {
-                const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
-                reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
-            }
+        if (pending_dst && j < WT * 4) {
+            const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
+            reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * TSTRIDE + 4 * c4);
         }
     };
     if (d.sv_rh && primary) park(hid, d.sv_rh + tile_n0 * W);
@@ -728,16 +687,12 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
         L2.preload();
         f32x16 h1[WT];
         L1.run(hid, h1, h, drain_piece);
-        drain_flush();
         D1_TICK(3);
         relu_inplace<WT>(h1);
         if (d.sv_h1) park(h1, d.sv_h1 + ((size_t)d.head_slot[hd] * d.Npad + tile_n0) * W);
         if (k > 32) { L2b.setup(w2h + 32 * LDW, p.b2[hd] + 32, LDW, k - 32, g, h); L2b.preload(); }
         const int nxt = next_head_m(head_mask, hd);
-        if (nxt < FDGS_NUM_HEADS) {
-            if (pk) L1.setup_packed(pk + (size_t)nxt * W * W, p.b1[nxt], W, g, h, lane_o); else L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h);
-            L1.preload();
-        }
+        if (nxt < FDGS_NUM_HEADS) { L1.setup(p.w1[nxt], p.b1[nxt], W, W, g, h); L1.preload(); }
         f32x16 o0 = zero16(), o1 = zero16();
         D1_TICK(4);
         if (small) {
@@ -755,7 +710,6 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
     // the last parked tile has no following layer to hide under
 #pragma unroll
     for (int j = 0; j < WT * 4; j++) drain_piece(j);
-    drain_flush();
     D1_TICK(7);
     }   // tile loop
 #ifdef FDGS_PROFILE_D1
@@ -767,21 +721,6 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 }
 
 #include "deform_fwd16.h"
-
-// The heads' W1 as the operand streams of the 32-Gaussian forward kernel's DenseIL walk: vector (KT floats) index (s * OT + ot) * 64 + lane
-// = W1[OT g + ot][KT rho(s, 0) + KT 4 h .. + KT - 1], lane = (g, h).  Same buffer layout as the 16-form's ([W0 slot][head 0] ... [head 4]).
-__global__ void __launch_bounds__(256) pack_weights32_kernel(PackArgs a) {
-    const int W = a.W, T = W / 32;
-    const int nv_head = W * W / T;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= FDGS_NUM_HEADS * nv_head) return;
-    const int hd = e / nv_head, k = e - hd * nv_head;
-    if (!a.head_on[hd]) return;
-    const int lane = k & 63, ot = (k >> 6) % T, s = k / (64 * T), g = lane & 31, h = lane >> 5;
-    const float* src = a.w1[hd] + (size_t)(T * g + ot) * W + T * rho(s, 0) + T * 4 * h;
-    float* dst = a.out + (size_t)a.F * W + (size_t)hd * W * W + (size_t)k * T;
-    for (int i = 0; i < T; i++) dst[i] = src[i];
-}
 
 // ------------------------------------------------------------------------------------------------ backward: prep
 // Per Gaussian: activation Jacobians -> packed pre-activation output gradients G[n][64]; direct (identity) paths.
@@ -2460,16 +2399,6 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         const bool form16 = tunable("FDGS_D1_FORM", 32) == 16 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         d.packed = reinterpret_cast<const float*>(out->packed);
         d.skew = tunable("FDGS_D16_SKEW", 600);
-        if (!form16 && out->packed && tunable("FDGS_D1_PACK32", 0)) {
-            FDGS_TIMED("pack_weights", stream);
-            PackArgs pa{};
-            pa.W = p->W; pa.F = d.F; pa.out = reinterpret_cast<float*>(out->packed);
-            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
-            const int nv = FDGS_NUM_HEADS * p->W * p->W / (p->W / 32);
-            hipLaunchKernelGGL(pack_weights32_kernel, dim3(cdiv(nv, 256)), dim3(256), 0, stream, pa);
-        } else if (!form16) {
-            d.packed = nullptr;
-        }
         if (form16) {
             FDGS_TIMED("pack_weights", stream);
             PackArgs pa{};

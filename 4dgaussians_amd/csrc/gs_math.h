@@ -1,6 +1,5 @@
-// gs_math.h -- per-Gaussian projection arithmetic (forward and backward), shared by the HIP kernels in
-// preprocess.hip and by the host-side arithmetic check tests/host_math_check.cpp (compiled with g++; that check
-// only exercises these inline functions against the oracle, it is not a product path).
+// gs_math.h -- per-Gaussian projection arithmetic (forward and backward) of the HIP kernels in preprocess.hip (written host / device
+// neutral: plain inline functions; checked stage by stage against the oracle through the kernels, tests/test_gpu_raster.py).
 //
 // Arithmetic follows SURVEY.md Appendix B.1 / B.5 (the un-vendored rasterizer the reference calls at
 // gaussian_renderer/__init__.py:120-128); the in-tree formulas it must agree with are

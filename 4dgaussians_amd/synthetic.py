@@ -164,6 +164,10 @@ class SynthModel(torch.nn.Module):
 
     def __init__(self, n, deform_cfg="dynerf_default", seed=6666, sh_degree=3, device="cpu", perturb_time_planes=0.1,
                  deformation=None, scene="cube"):
+        """`perturb_time_planes` (name kept from SURVEY 8d, which perturbs the time planes only): 0.1 * N(0, 1) is added to EVERY plane of the
+        HexPlane field -- spatial planes too -- so that no factor of the six-plane product is constant in any coordinate (the reference's
+        initialisation leaves the time planes at exactly one, scene/hexplane.py:64-67, and the deformation would not depend on t at all).
+        Every measured number of this repository is on this generator; changing it would change the benchmark scene."""
         super().__init__()
         from . import deformation as D
         g = make_gaussians(n, seed=seed, sh_degree=sh_degree, scene=scene)

@@ -69,22 +69,6 @@ def test_deform_parity_16_gaussian_form_of_the_forward_kernel(cfg, n, t, monkeyp
     _parity(cfg, n, True, scalar_time=t)
 
 
-def test_packed_operand_streams_of_the_32_form_change_nothing(monkeypatch):
-    """FDGS_D1_PACK32=1: the 32-Gaussian forward kernel reading the heads' W1 as packed operand streams -- bit-identical outputs (same
-    products in the same order, only the addresses of the operands differ)."""
-    fd = _fdgs()
-    dev = torch.device("cuda:0")
-    pc = synthetic.SynthModel(5000, "dynerf_default", seed=3).to(dev)
-    outs = []
-    for pack in ("0", "1"):
-        monkeypatch.setenv("FDGS_D1_PACK32", pack)
-        with torch.no_grad():
-            outs.append(fd.deformation.deform(pc._deformation, pc._xyz, pc._scaling, pc._rotation, pc._opacity, shs_dc=pc._features_dc,
-                                              shs_rest=pc._features_rest, time=0.4, activate=True))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("cfg,n,t", [("dynerf_default", 2100, 0.37), ("hypernerf_default", 700, 1.0), ("dnerf_bouncingballs", 900, 0.0)])
 def test_deform_parity_one_frame_time(cfg, n, t):
     """render() hands ONE frame time to all Gaussians: the plane-gradient kernel then privatises the three time planes in
