@@ -111,6 +111,8 @@ SYMBOLS = {
     "fdgs_deform_bwd": (c_int, [c_void_p, POINTER(DeformParams), POINTER(DeformGrads)]),
     "fdgs_deform_bwd_live_tiles": (c_int, [c_void_p, POINTER(DeformParams), c_void_p, POINTER(c_uint32)]),
     "fdgs_l1_stats": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "fdgs_l1_stats_scratch_bytes": (c_int, [POINTER(c_size_t)]),
+    "fdgs_l1_stats_assign": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "fdgs_image_loss_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdgs_image_loss_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "fdgs_plane_regulation": (c_int, [c_void_p, c_int, POINTER(RegPlane), c_float, c_void_p, c_void_p]),

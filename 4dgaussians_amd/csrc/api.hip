@@ -40,8 +40,14 @@ void timing_end(void* rec, hipStream_t stream) {
 // same-address float atomics retire at ~80 M/s on MI355X, so the 1 024 of the 512 x 256-thread form of rounds 1-3 were more
 // than half of its 22 us.
 constexpr int L1S_THREADS = 1024;
+// ASSIGN: the workgroups leave their partial sums in `scratch` (float2 per workgroup) and take a ticket; the last one adds the partials in
+// workgroup order and ASSIGNS acc[0..2] -- deterministic, no same-address float atomics, no zero fill of `acc` by the caller; the ticket
+// counter (scratch word 2 * L1S_MAX_BLOCKS, zero at allocation) resets itself.
+constexpr int L1S_MAX_BLOCKS = 256;
+template <bool ASSIGN>
 __global__ void __launch_bounds__(L1S_THREADS) l1_stats_kernel(size_t n, size_t n4, const float* __restrict__ a, const float* __restrict__ b,
-                                                               float scale, float* __restrict__ grad, float* __restrict__ acc) {
+                                                               float scale, float* __restrict__ grad, float* __restrict__ acc,
+                                                               float* __restrict__ scratch) {
     float s1 = 0.f, s2 = 0.f;
     // n4 = number of 16-byte groups handled with float4 accesses (0 when a pointer is not 16-byte aligned), scalar tail
     const float4* a4 = reinterpret_cast<const float4*>(a);
@@ -74,12 +80,42 @@ __global__ void __launch_bounds__(L1S_THREADS) l1_stats_kernel(size_t n, size_t 
     __shared__ float w1[L1S_THREADS / 64], w2[L1S_THREADS / 64];
     if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = s1; w2[threadIdx.x >> 6] = s2; }
     __syncthreads();
+    __shared__ unsigned last_block;
     if (threadIdx.x == 0) {
         float t1 = 0.f, t2 = 0.f;
         for (int k = 0; k < L1S_THREADS / 64; k++) { t1 += w1[k]; t2 += w2[k]; }
-        atomicAdd(&acc[0], t1);
-        atomicAdd(&acc[1], t2);
-        if (blockIdx.x == 0) atomicAdd(&acc[2], (float)n);
+        if constexpr (ASSIGN) {
+            scratch[2 * blockIdx.x] = t1; scratch[2 * blockIdx.x + 1] = t2;
+            __threadfence();
+            unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * L1S_MAX_BLOCKS);
+            last_block = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        } else {
+            atomicAdd(&acc[0], t1);
+            atomicAdd(&acc[1], t2);
+            if (blockIdx.x == 0) atomicAdd(&acc[2], (float)n);
+        }
+    }
+    if constexpr (ASSIGN) {
+        __syncthreads();
+        if (last_block) {       // (uniform over the workgroup) the partials of all workgroups, one per thread, added in a fixed tree order
+            __threadfence();
+            float u1 = 0.f, u2 = 0.f;
+            if (threadIdx.x < gridDim.x) {
+                u1 = __hip_atomic_load(&scratch[2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u2 = __hip_atomic_load(&scratch[2 * threadIdx.x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = u1; w2[threadIdx.x >> 6] = u2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float v1 = 0.f, v2 = 0.f;
+                for (int k = 0; k < L1S_MAX_BLOCKS / 64; k++) { v1 += w1[k]; v2 += w2[k]; }
+                acc[0] = v1; acc[1] = v2; acc[2] = (float)n;
+                *reinterpret_cast<unsigned*>(scratch + 2 * L1S_MAX_BLOCKS) = 0u;
+            }
+        }
     }
 }
 }  // namespace fdgs
@@ -139,7 +175,27 @@ extern "C" int fdgs_l1_stats(void* stream_, size_t n, const float* a, const floa
     int blocks = (int)(((aligned ? n / 4 : n) + L1S_THREADS - 1) / L1S_THREADS);
     if (blocks < 1) blocks = 1;
     if (blocks > 256) blocks = 256;   // one workgroup per CU; two atomics per workgroup on the same two words
-    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel, dim3(blocks), dim3(L1S_THREADS), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc); }
+    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel<false>, dim3(blocks), dim3(L1S_THREADS), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc, (float*)nullptr); }
+    FDGS_LAUNCH_CHECK("l1_stats", 0, stream);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_l1_stats_scratch_bytes(size_t* bytes) {
+    FDGS_REQUIRE(bytes, "bytes is NULL");
+    *bytes = (2 * L1S_MAX_BLOCKS + 4) * sizeof(float);
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_l1_stats_assign(void* stream_, size_t n, const float* a, const float* b, float grad_scale, float* grad_out_opt,
+                                    float* acc, void* scratch) {
+    FDGS_REQUIRE(a && b && acc && scratch, "NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_out_opt) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    int blocks = (int)(((aligned ? n / 4 : n) + L1S_THREADS - 1) / L1S_THREADS);
+    if (blocks < 1) blocks = 1;
+    if (blocks > L1S_MAX_BLOCKS) blocks = L1S_MAX_BLOCKS;
+    { FDGS_TIMED("l1_stats", stream); hipLaunchKernelGGL(l1_stats_kernel<true>, dim3(blocks), dim3(L1S_THREADS), 0, stream, n, n4, a, b, grad_scale, grad_out_opt, acc, reinterpret_cast<float*>(scratch)); }
     FDGS_LAUNCH_CHECK("l1_stats", 0, stream);
     return FDGS_OK;
 }

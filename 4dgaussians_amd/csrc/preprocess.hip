@@ -128,8 +128,15 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
         a.keys[i] = key;
         a.ids[i] = (uint32_t)i;
     }
-    uint32_t s = wave_sum_u32(my_tiles);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.total, s);
+    // ONE atomic per workgroup on the pair total (4 688 per-wave atomics on one address were serialised at the L2: round 4)
+    __shared__ uint32_t wsum[4];
+    const uint32_t s = wave_sum_u32(my_tiles);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(a.total, t);
+    }
     if (i == 0) a.total[2] = a.cull ? 1u : 0u;   // the pair expansion reads which list semantics the counts have
 }
 

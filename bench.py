@@ -25,6 +25,7 @@ import types
 T_PROCESS_START = time.perf_counter()
 
 import torch
+from ctypes import c_size_t as ctypes_size_t
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -182,6 +183,9 @@ def run(args, make_step=None):
     pending = [None, None]
     acc = accs[0]
     dimg = torch.empty(3, H, W, device=dev)
+    nb_ = ctypes_size_t()
+    fdgs._lib.check(L.fdgs_l1_stats_scratch_bytes(nb_))
+    l1_scratch = torch.zeros(nb_.value, dtype=torch.uint8, device=dev)      # (zero once: holds the kernel's self-resetting ticket)
     st = fdgs._lib.stream_ptr
     ptr = fdgs._lib.ptr
     info = {}
@@ -199,8 +203,8 @@ def run(args, make_step=None):
             acc_ = accs[b_]
             if pending[b_] is not None:
                 pending[b_].wait()          # (the reduction issued two steps ago: long done; orders the buffer's reuse)
-            acc_.zero_()
-            fdgs._lib.check(L.fdgs_l1_stats(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc_)))
+            # L1 statistics ASSIGNED to the buffer (no fill launch, no same-address float atomics) + dL/dimage in the same pass
+            fdgs._lib.check(L.fdgs_l1_stats_assign(st(), img.numel(), ptr(img), ptr(target), 1.0 / img.numel(), ptr(dimg), ptr(acc_), ptr(l1_scratch)))
             img.backward(dimg)
             pending[b_] = par.allreduce_loss_stats(acc_, async_op=True)   # the only cross-GPU exchange of the path, under the next step
             info["radii"], info["vsp"], info["vis"], info["acc"] = res["radii"], res["viewspace_points"], res["visibility_filter"], acc_

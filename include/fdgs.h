@@ -270,6 +270,12 @@ int fdgs_deform_bwd_live_tiles(void* stream, const fdgs_deform_params* p, const 
  * ---------------------------------------------------------------------------------------------------------- */
 int fdgs_l1_stats(void* stream, size_t n, const float* a, const float* b, float grad_scale, float* grad_out_opt,
                   float* acc);
+/* Same statistics ASSIGNED to acc[3] (no zero fill by the caller, no same-address float atomics, sums added in a fixed order: deterministic).
+ * `scratch`: fdgs_l1_stats_scratch_bytes() bytes of device memory, zero-filled ONCE at allocation (it holds a self-resetting ticket counter);
+ * one scratch per stream. */
+int fdgs_l1_stats_scratch_bytes(size_t* bytes);
+int fdgs_l1_stats_assign(void* stream, size_t n, const float* a, const float* b, float grad_scale, float* grad_out_opt,
+                         float* acc, void* scratch);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Image losses of the step right after render() (train.py:201-214): l1_loss (utils/loss_utils.py:20-21), the sum of

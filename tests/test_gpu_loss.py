@@ -145,3 +145,31 @@ def test_no_grad_evaluation_allocates_no_backward_buffers(monkeypatch):
     assert torch.allclose(a, a2) and torch.allclose(b, b2)
     (a2 + b2 + losses.l1_loss(img, gt)).backward()
     assert img.grad is not None and torch.isfinite(img.grad).all()
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 3 * 1014 * 1352, 1_000_003])
+def test_l1_stats_assign_is_deterministic_and_needs_no_zero_fill(n):
+    """fdgs_l1_stats_assign: [sum |a-b|, sum (a-b)^2, n] ASSIGNED to a dirty buffer through per-workgroup partials and a ticket (no
+    same-address float atomics): equal to torch to float rounding, bit-identical from run to run, ticket self-resetting."""
+    import ctypes
+    fd = importlib.import_module("4dgaussians_amd")
+    L = fd._lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    a, b = torch.rand(n, generator=g).to(dev), torch.rand(n, generator=g).to(dev)
+    nb = ctypes.c_size_t()
+    fd._lib.check(L.fdgs_l1_stats_scratch_bytes(nb))
+    scratch = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+    grad = torch.empty(n, device=dev)
+    outs = []
+    for rep in range(3):
+        acc = torch.full((3,), float("nan"), device=dev)              # (no zero fill: the kernel assigns)
+        fd._lib.check(L.fdgs_l1_stats_assign(fd._lib.stream_ptr(), n, fd._lib.ptr(a), fd._lib.ptr(b), 0.5, fd._lib.ptr(grad), fd._lib.ptr(acc),
+                                             fd._lib.ptr(scratch)))
+        outs.append(acc.cpu())
+    d = (a - b).double()
+    assert abs(float(outs[0][0]) - float(d.abs().sum())) <= 2e-6 * max(float(d.abs().sum()), 1.0)
+    assert abs(float(outs[0][1]) - float((d * d).sum())) <= 2e-6 * max(float((d * d).sum()), 1.0)
+    assert float(outs[0][2]) == float(n)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(grad, 0.5 * torch.sign(a - b))
