@@ -703,7 +703,8 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
             "grad_rel_l2_vs_float64_oracle": att["grad_rel_l2_vs_float64_raw"],
             "grad_rel_l2_vs_float64_oracle_kink_rows_attributed": att["grad_rel_l2_vs_float64_kink_rows_attributed"],
             "kink_rows": att["kink_rows"], "n_kink_rows": att["n_kink_rows"], "max_kink_rows": att["max_kink_rows"],
-            "heavy_rows_within_tol_rowwise": att["heavy_rows_within_tol_rowwise"], "grad_rule": att["rule"],
+            "heavy_rows_within_tol_rowwise": att["heavy_rows_within_tol_rowwise"], "unexplained_rows": att["unexplained_rows"],
+            "n_unexplained_rows": att["n_unexplained_rows"], "grad_rule": att["rule"],
             "grad_ok": att["ok"], "grad_failures": att["failures"],
             # for information: the same HIP gradients against the oracle's own float32 autograd (which has the same kinks as any float32 evaluation)
             "grad_rel_l2_vs_float32_oracle_info": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},

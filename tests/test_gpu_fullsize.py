@@ -83,7 +83,8 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     worst = sorted(per_tensor.items(), key=lambda kv: -kv[1])[:4]
     print("   group rel-L2 vs float64 oracle (raw): " + ", ".join(f"{k}={v:.2e}" for k, v in rep["grad_rel_l2_vs_float64_raw"].items()) + f", viewspace={vs:.2e}")
     print("   with kink rows attributed:            " + ", ".join(f"{k}={v:.2e}" for k, v in rep["grad_rel_l2_vs_float64_kink_rows_attributed"].items()))
-    print(f"   kink rows ({rep['n_kink_rows']} of {N}, allowed {rep['max_kink_rows']}): {rep['kink_rows']}  heavy rows: {rep['heavy_rows_within_tol_rowwise']}")
+    print(f"   kink rows ({rep['n_kink_rows']} of {N}, allowed {rep['max_kink_rows']}): {rep['kink_rows']}  heavy rows: {rep['heavy_rows_within_tol_rowwise']}  "
+          f"unexplained rows (counted in the figures above): {rep['unexplained_rows']}")
     print("   worst tensors (raw): " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
     assert rep["ok"], rep["failures"]
     assert vs <= 1e-3, vs
