@@ -363,17 +363,19 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
         saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     out.saved = ptr(saved)
     st.saved_act = saved
-    # scratch for the operand-stream copy of W0 / W1 the 16-Gaussian form of the forward kernel reads (re-packed by every forward: the
-    # weights change every optimizer step); one persistent buffer per (device, size): forwards on a stream are ordered
-    nbytes = _lib.c_size_t()
-    check(L.fdgs_deform_pack_bytes(p, nbytes))
-    key = (dev, nbytes.value)
-    packed = _pack_scratch.get(key)
-    if packed is None:
-        if len(_pack_scratch) > 8:
-            _pack_scratch.clear()
-        packed = _pack_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    out.packed = ptr(packed)
+    # scratch for the operand-stream copy of W0 / W1 that the 16-Gaussians-per-wave form of the forward kernel reads (FDGS_D1_FORM=16; the
+    # library re-packs the weights into it in front of every forward).  Only handed over when that form is asked for; one persistent buffer
+    # per (device, stream, size): forwards on one stream are ordered, forwards on different streams must not share it.
+    if os.environ.get("FDGS_D1_FORM", "32") == "16":
+        nbytes = _lib.c_size_t()
+        check(L.fdgs_deform_pack_bytes(p, nbytes))
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, nbytes.value)
+        packed = _pack_scratch.get(key)
+        if packed is None:
+            if len(_pack_scratch) > 8:
+                _pack_scratch.clear()
+            packed = _pack_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out.packed = ptr(packed)
     check(L.fdgs_deform_fwd(stream_ptr(), p, out))
     st.cfg, st.p = cfg, p
     st.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape, sh_b=None if sh_b is None else sh_b.shape)

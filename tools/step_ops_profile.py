@@ -17,6 +17,10 @@ cams = [c.to(dev) for c in syn.orbit_cameras(W, H, n=16)]
 target = torch.rand(3, H, W, device=dev)
 params = [p for p in pc.parameters() if p.requires_grad]
 acc = torch.zeros(3, device=dev)
+import ctypes
+_nb = ctypes.c_size_t()
+fdgs._lib.check(fdgs._lib.lib().fdgs_l1_stats_scratch_bytes(_nb))
+l1_scratch = torch.zeros(_nb.value, dtype=torch.uint8, device=dev)
 dimg = torch.empty(3, H, W, device=dev)
 L = fdgs._lib.lib()
 pipe, bg = syn.PipelineParams(), torch.zeros(3, device=dev)
@@ -27,9 +31,8 @@ def step(i):
         p_.grad = None
     res = fdgs.render(cams[i % len(cams)], pc, pipe, bg, stage="fine")
     img = res["render"]
-    acc.zero_()
-    fdgs._lib.check(L.fdgs_l1_stats(fdgs._lib.stream_ptr(), img.numel(), fdgs._lib.ptr(img), fdgs._lib.ptr(target), 1.0 / img.numel(),
-                                    fdgs._lib.ptr(dimg), fdgs._lib.ptr(acc)))
+    fdgs._lib.check(L.fdgs_l1_stats_assign(fdgs._lib.stream_ptr(), img.numel(), fdgs._lib.ptr(img), fdgs._lib.ptr(target), 1.0 / img.numel(),
+                                           fdgs._lib.ptr(dimg), fdgs._lib.ptr(acc), fdgs._lib.ptr(l1_scratch)))
     img.backward(dimg)
 
 
