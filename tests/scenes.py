@@ -30,55 +30,4 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / d) if d > 0 else float(np.linalg.norm(a))
 
 
-def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32, both=False):
-    """render() restated with the CPU oracles: deformation oracle (pinned to the reference modules) -> C rasterizer oracle
-    forward -> L1-loss image gradient against a seeded random target -> C analytic backward -> torch-CPU autograd through the
-    deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, dL/ddepth, {parameter name: gradient or None}).
-    `grad_dtype=torch.float64`: the autograd pass through the deformation is a float64 re-evaluation of the same oracle function fed
-    with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64) -- THE gradient reference of the full-size
-    checks; the returned dict then also carries "__ctx" = (sd, flags, leaves, time, upstream gradients), what oracle.parity.attribute needs
-    to name the rows on which an implementation took a ReLU / texel-cell decision the other way.  `both=True` also returns the float32
-    autograd gradients under "__float32" (tools only)."""
-    from oracle import deform_oracle as DO
-    from oracle.raster_oracle import RasterOracle
-    n = pc._xyz.shape[0]
-    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "poc" not in k and "aabb" not in k)
-          for k, v in pc._deformation.state_dict().items()}
-    leaves = {k: getattr(pc, k).detach().clone().requires_grad_(True)
-              for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")}
-    shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
-    if stage == "fine":
-        m3, sc, rot, op, sh = DO.deform_forward(sd, pc._deformation.args, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"],
-                                                leaves["_opacity"], shs, torch.full((n, 1), cam.time), activate=True)
-    else:
-        m3, sh = leaves["_xyz"], shs
-        sc, op = torch.exp(leaves["_scaling"]), torch.sigmoid(leaves["_opacity"])
-        rot = torch.nn.functional.normalize(leaves["_rotation"])
-    f = lambda x: np.ascontiguousarray(x.detach().numpy())
-    H, W = cam.image_height, cam.image_width
-    o = RasterOracle(means3D=f(m3), scales=f(sc), rotations=f(rot), opacities=f(op), shs=f(sh), viewmatrix=f(cam.world_view_transform),
-                     projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center), bg=np.zeros(3, np.float32), image_height=H,
-                     image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
-    rng = np.random.default_rng(target_seed)
-    target = rng.random(o.color.shape).astype(np.float32)
-    dc = (np.sign(o.color - target) / o.color.size).astype(np.float32)
-    dd = (rng.standard_normal(o.depth.shape).astype(np.float32) / o.depth.size) if with_depth_grad else None
-    go = o.backward(dc, dd)
-    outs = [m3, sc, rot, op, sh]
-    gouts = [torch.tensor(go["means3D"]), torch.tensor(go["scales"]), torch.tensor(go["rotations"]),
-             torch.tensor(go["opacities"]).reshape(op.shape), torch.tensor(go["shs"]).reshape(sh.shape)]
-    if grad_dtype != torch.float32 and stage == "fine":
-        grads = DO.backward_float64(sd, pc._deformation.args, leaves, cam.time, gouts)
-        grads["__ctx"] = (sd, pc._deformation.args, {k: v.detach() for k, v in leaves.items()}, cam.time, gouts)
-        if both:
-            wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
-            wnames = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
-            g32 = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
-            grads["__float32"] = {k: (None if g is None else g.numpy()) for k, g in zip(wnames, g32)}
-    else:
-        wanted = list(leaves.values()) + ([v for v in sd.values() if v.requires_grad] if stage == "fine" else [])
-        wnames = list(leaves.keys()) + (["_deformation." + k for k, v in sd.items() if v.requires_grad] if stage == "fine" else [])
-        g_ref = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
-        grads = {k: (None if g is None else g.numpy()) for k, g in zip(wnames, g_ref)}
-    grads["__means2D"] = go["means2D"]
-    return o, dc, dd, grads
+from oracle.chain import oracle_render_chain  # noqa: E402,F401  (the chain lives with the oracles: smoke() and bench.py use it too)
