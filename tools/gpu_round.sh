@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/gpu_round.sh TAG -- one GPU-box pass: parity tests, bench line (with CPU baseline + oracle parity), rocprofv3 kernel
-# stats; optional (PMC=1) SQ counters and per-workload HBM traffic passes; optional EXTRA_WORKLOADS bench lines.
+# stats; optional (PMC=1) SQ counters and per-workload HBM traffic passes; optional EXTRA_WORKLOADS bench lines; optional (SHELL_SCENE=1)
+# bench line + kernel stats of the shell scene.
 # Outputs land in gpurun_out/TAG_*; copy what should be judged into profiles/.
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -57,6 +58,23 @@ import json,sys
 d=json.load(open('gpurun_out/${TAG}_bench_$WL.json')); print('$WL', round(d['value'],1), 'frames/s', d['config']['num_rendered'], d['kernels_ms_per_step'])" 2>&1 | cut -c1-500
   if [ -n "$PMC_EXTRA" ]; then prof_one $WL _$WL > /dev/null; pmc_one $WL _$WL; fi
 done
+if [ -n "$SHELL_SCENE" ]; then
+  # the second scene statistic (bench.py --scene shell): its own bench line with oracle parity + rocprofv3 kernel stats
+  timeout 300 python bench.py --scene shell --steps 10 --warmup 3 --repeats 5 --cpu-frames 1 --no-extras > gpurun_out/${TAG}_bench_shell.json 2> gpurun_out/${TAG}_bench_shell.err
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_shell -o trace --output-format csv -- python $R/bench.py --scene shell --steps 20 --warmup 4 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  cd $R
+  python - <<PY
+import csv, glob
+f = glob.glob("gpurun_out/${TAG}_prof_shell/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    out = ["%-60s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct")]
+    for r in rows[:28]:
+        out.append("%-60s %8s %12.3f %10.2f %7s" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    open("gpurun_out/${TAG}_kernel_stats_shell.txt", "w").write("\n".join(out) + "\n")
+PY
+fi
 # drop the bulky raw traces from what travels back (summaries stay)
 rm -rf gpurun_out/${TAG}_prof*/ gpurun_out/${TAG}_pmc_FETCH_SIZE* gpurun_out/${TAG}_pmc_WRITE_SIZE* gpurun_out/${TAG}_pmc_sq/ 2>/dev/null
 exit 0
