@@ -142,3 +142,47 @@ def run_hip(student, cams, targets, iters, decay=0.01, device="cuda:0"):
     with torch.no_grad():
         final = [float(fdgs.losses.psnr(fdgs.render(c, pc, pipe, bg, stage="fine")["render"], t).mean()) for c, t in zip(cg, tg)]
     return curve, final
+
+
+def run_reference_loop_over_shim(student, cams, targets, iters, decay=0.01, device="cuda:0"):
+    """The same fit through the REFERENCE's own code on the GPU: the reference's `render()` (gaussian_renderer/__init__.py:18-138) and the
+    reference's `deform_network` (scene/deformation.py:161) -- byte-compiled into oracle/_ref, imported sourceless -- over this repository's
+    `diff_gaussian_rasterization` shim, the reference's L1 (utils/loss_utils.py:20-21: mean |a - b|) and `torch.optim.Adam(eps=1e-15)` as
+    scene/gaussian_model.py:184 constructs it.  What the reference's train loop executes per iteration, minus data loading and densification,
+    with only the rasterizer replaced."""
+    from oracle import ref_modules
+    ns = ref_modules.load()
+    dev = torch.device(device)
+    net = ns.deform_network(student._deformation.args)
+    net.load_state_dict(student._deformation.state_dict(), strict=True)
+    pc = synthetic.SynthModel(student._xyz.shape[0], "dynerf_default", seed=0, deformation=net)
+    with torch.no_grad():
+        for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+            getattr(pc, k).copy_(getattr(student, k))
+    pc = pc.to(dev)
+    mlp = list(net.get_mlp_parameters())
+    grid = list(net.get_grid_parameters())
+    groups = [{"params": [pc._xyz], "lr": LRS["xyz"]}, {"params": mlp, "lr": LRS["deformation"]}, {"params": grid, "lr": LRS["grid"]},
+              {"params": [pc._features_dc], "lr": LRS["f_dc"]}, {"params": [pc._features_rest], "lr": LRS["f_rest"]},
+              {"params": [pc._opacity], "lr": LRS["opacity"]}, {"params": [pc._scaling], "lr": LRS["scaling"]},
+              {"params": [pc._rotation], "lr": LRS["rotation"]}]
+    opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    base = [g["lr"] for g in groups]
+    tg = [torch.tensor(t, device=dev) for t in targets]
+    cg = [c.to(dev) for c in cams]
+    pipe, bg = synthetic.PipelineParams(), torch.zeros(3, device=dev)
+    psnr = lambda a, b: float(10.0 * torch.log10(1.0 / ((a - b) ** 2).mean().clamp_min(1e-20)))
+    curve = []
+    for it in range(iters):
+        for g, b in zip(opt.param_groups, base):
+            g["lr"] = b * decay ** (it / max(iters - 1, 1))
+        v = it % len(cams)
+        opt.zero_grad(set_to_none=True)
+        img = ns.render(cg[v], pc, pipe, bg, stage="fine")["render"]
+        loss = torch.abs(img - tg[v]).mean()
+        loss.backward()
+        curve.append(psnr(img.detach(), tg[v]))
+        opt.step()
+    with torch.no_grad():
+        final = [psnr(ns.render(c, pc, pipe, bg, stage="fine")["render"], t) for c, t in zip(cg, tg)]
+    return curve, final

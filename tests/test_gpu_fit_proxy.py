@@ -30,3 +30,24 @@ def test_fit_through_hip_path_matches_fit_through_oracle_chain():
     assert abs(m_hip - m_ref) < 0.05
     assert max(abs(a - b) for a, b in zip(f_ref, f_hip)) < 0.1      # every single view, too
     assert drift[:40].max() < 0.01            # identical start: the first iterations agree to rounding
+
+
+def test_fit_through_the_references_own_loop_code_over_the_shim_matches_the_fused_path():
+    """The reference's own render() + deform_network + L1 + torch.optim.Adam on the GPU, only the rasterizer replaced (the shim), against
+    fdgs.render + fdgs.losses + FusedAdam: same 300-iteration fit, final PSNR within north_star's 0.05 dB, every view within 0.1 dB."""
+    from oracle import ref_modules
+    if not ref_modules.available():
+        pytest.skip("oracle/_ref not built (python -m oracle.build_ref where /root/reference exists)")
+    iters = 300
+    student, cams, targets = fit_proxy.make_problem()
+    c_ref, f_ref = fit_proxy.run_reference_loop_over_shim(student, cams, targets, iters)
+    c_hip, f_hip = fit_proxy.run_hip(student, cams, targets, iters)
+    m_ref, m_hip = float(np.mean(f_ref)), float(np.mean(f_hip))
+    head = float(np.mean(c_ref[:6]))
+    drift = np.abs(np.array(c_ref) - np.array(c_hip))
+    print(f"PSNR over the {len(cams)} training views: start {head:.2f} dB -> reference loop over the shim {m_ref:.3f} dB, fused HIP path {m_hip:.3f} dB "
+          f"(diff {m_hip - m_ref:+.4f} dB); curve drift first 50 max {drift[:50].max():.4f}, overall max {drift.max():.4f} dB")
+    assert m_ref > head + 3.0
+    assert abs(m_hip - m_ref) < 0.05
+    assert max(abs(a - b) for a, b in zip(f_ref, f_hip)) < 0.1
+    assert drift[:40].max() < 0.01
