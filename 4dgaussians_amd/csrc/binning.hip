@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
                                                            int gx, uint32_t* __restrict__ pair_tile,
                                                            uint32_t* __restrict__ pair_gid, uint32_t* __restrict__ ranges_zero, uint32_t ranges_n) {
     // (the per-tile ranges tile_ranges_kernel fills at the end of the stage: cleared here, on the way, instead of by a memset node)
-    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ranges_n; k += gridDim.x * 256) ranges_zero[k] = 0u;
+    if (blockIdx.y == 0)
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ranges_n; k += gridDim.x * 256) ranges_zero[k] = 0u;
     __shared__ uint32_t s_end[256];
     __shared__ uint32_t s_gid[256];
     __shared__ uint2 s_rect[256];
@@ -340,7 +341,10 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
     const uint32_t start = (first == 0) ? 0u : offsets_incl[first - 1];
     const uint32_t stop = s_end[255];
     (void)cnt;
-    for (uint32_t p = start + t; p < stop; p += 256) {
+    // gridDim.y workgroups share one block of 256 depth-consecutive Gaussians and interleave its pairs: the nearest Gaussians (the first
+    // blocks) cover 60+ tiles each, five times the average.  Measured: 2 workgroups per block 0.036 ms, 1: 0.042, 4: 0.042, 8: 0.064 (the
+    // staging of the 256 Gaussians -- two dependent gathers -- is repeated per workgroup)
+    for (uint32_t p = start + t + 256u * blockIdx.y; p < stop; p += 256u * gridDim.y) {
         // smallest j with s_end[j] > p
         int lo = 0, hi = 255;
 #pragma unroll
@@ -361,13 +365,30 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
     }
 }
 
+// four pairs per thread (one 16-byte load + the two neighbours): a quarter of the threads of the one-pair form, whose 16.6 k workgroups of
+// three dependent 4-byte loads each were launch / latency bound (10.8 us for 17 MB)
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ pair_tile,
                                                           uint2* __restrict__ ranges) {
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= R) return;
-    const uint32_t tcur = pair_tile[p];
-    if (p == 0 || pair_tile[p - 1] != tcur) ranges[tcur].x = p;
-    if (p == R - 1 || pair_tile[p + 1] != tcur) ranges[tcur].y = p + 1;
+    const uint32_t p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= R) return;
+    uint32_t t[6];          // t[0] = tile of pair p0 - 1, t[1..4] = pairs p0 .. p0 + 3, t[5] = pair p0 + 4
+    if (p0 + 4 <= R) {
+        const uint4 q = *reinterpret_cast<const uint4*>(pair_tile + p0);
+        t[1] = q.x; t[2] = q.y; t[3] = q.z; t[4] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[1 + k] = p0 + k < R ? pair_tile[p0 + k] : 0xFFFFFFFFu;
+    }
+    t[0] = p0 > 0 ? pair_tile[p0 - 1] : 0xFFFFFFFFu;
+    t[5] = p0 + 4 < R ? pair_tile[p0 + 4] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t p = p0 + k;
+        if (p >= R) break;
+        const uint32_t tcur = t[1 + k];
+        if (p == 0 || t[k] != tcur) ranges[tcur].x = p;
+        if (p == R - 1 || t[2 + k] != tcur) ranges[tcur].y = p + 1;
+    }
 }
 
 int validate_raster_params(const fdgs_raster_params* p);
@@ -453,7 +474,7 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     }
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
-    { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
+    { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256), tunable("FDGS_EXPAND_SPLIT", 2)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
                        at<uint32_t>(geom, gl.total), il.gx,
                        at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2)); }
@@ -469,7 +490,7 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.gid1), (size_t)R * 4,
                                       hipMemcpyDeviceToDevice, stream));
     }
-    { FDGS_TIMED("tile_ranges", stream); hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 256)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
+    { FDGS_TIMED("tile_ranges", stream); hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 1024)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
                        at<uint2>(img, il.ranges)); }
     FDGS_LAUNCH_CHECK("tile_ranges", p->debug, stream);
     return FDGS_OK;
