@@ -2300,6 +2300,9 @@ static int dispatch_wf(int W, int F, hipStream_t stream, int blocks, const Arg& 
 #undef FDGS_CASE
     return fail(FDGS_E_INVALID, "%s", "unsupported (net_width, C*L) combination");
 }
+// floats of the SH head's stream in the ring form of deform_fwd16_kernel (pack_weights16_kernel, third segment): per output group the
+// group's W1 stages + four stages of its second-layer share
+static int sh_ring_floats(int W) { const int OT = W / 16, OH = OT / 4, HV = OT / 4; return OH * (4 * HV + 4) * 1024; }
 template <int WT, int FCH>
 struct FwdLauncher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
@@ -2310,6 +2313,12 @@ template <int WT, int FCH>
 struct Fwd16Launcher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
         if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2>), dim3(blocks), dim3(256), 0, s, d);
+    }
+};
+template <int WT, int FCH>
+struct Fwd16RingLauncher {
+    static void go(hipStream_t s, int blocks, const DeformDev& d) {
+        if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2, true>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
 template <int WT, int FCH, bool SAVED>
@@ -2396,7 +2405,12 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         static int cus = 0;
         if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
         // 16-Gaussian form (deform_fwd16.h): two workgroups per CU, needs whole float4 texel quarters per lane group (C % 16 == 0)
-        const bool form16 = tunable("FDGS_D1_FORM", 32) == 16 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
+        // which form of the forward kernel: 16 (default where it applies: two waves per SIMD; in the frame, where the gather starts on cold
+        // caches behind the previous frame's backward, it measured 5 - 7 % faster than the 32-form on every workload, profiles/r04_d1_forms.txt)
+        // | 32 | 17 (= 16 with the operand streams handed through an LDS ring; measured no faster)
+        const int form_req = tunable("FDGS_D1_FORM", 16);
+        const bool form16 = (form_req == 16 || form_req == 17) && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
+        const bool ring = form16 && form_req == 17;
         d.packed = reinterpret_cast<const float*>(out->packed);
         d.skew = tunable("FDGS_D16_SKEW", 600);
         if (form16) {
@@ -2404,7 +2418,8 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
             PackArgs pa{};
             pa.w0 = p->w0; pa.W = p->W; pa.F = d.F; pa.out = reinterpret_cast<float*>(out->packed);
             for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
-            const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4;
+            pa.w2_sh = p->w2[FDGS_HEAD_SHS]; pa.ring = ring ? 1 : 0;
+            const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4 + (ring ? sh_ring_floats(p->W) / 4 : 0);
             hipLaunchKernelGGL(pack_weights16_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, pa);
         }
         const int want = tunable("FDGS_D1_WGS", form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
@@ -2417,7 +2432,8 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
         d.prof = prof_dev;
 #endif
-        rc = form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+        rc = ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
+                  : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
 #ifdef FDGS_PROFILE_D1
         {
             static int reports = 0;
@@ -2431,6 +2447,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
                 for (int i = 0; i < 8; i++) tot += (double)hb[i];
                 fprintf(stderr, "[D1 profile] %llu waves, cycles per wave:\n", hb[8]);
                 for (int i = 0; i < 8; i++) fprintf(stderr, "  %-44s %12.0f  (%.1f %%)\n", names[i], (double)hb[i] / (double)hb[8], 100.0 * hb[i] / tot);
+                if (hb[9] || hb[10]) fprintf(stderr, "  of which: ring commit vmcnt(0) %.0f, s_barrier %.0f\n", (double)hb[9] / (double)hb[8], (double)hb[10] / (double)hb[8]);
             }
         }
 #endif
@@ -2444,7 +2461,7 @@ extern "C" int fdgs_deform_pack_bytes(const fdgs_deform_params* p, size_t* bytes
     int rc = validate_deform(p);
     if (rc) return rc;
     FDGS_REQUIRE(bytes, "bytes is NULL");
-    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W) * sizeof(float);
+    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W + (size_t)sh_ring_floats(p->W)) * sizeof(float);
     return FDGS_OK;
 }
 

@@ -61,11 +61,16 @@ def test_deform_forward_backward_parity(cfg, n, activate):
 
 @pytest.mark.parametrize("cfg,n,t", [("dnerf_bouncingballs", 1000, None), ("hypernerf_default", 257, None), ("dynerf_default", 1531, None),
                                      ("dynerf_default", 31, None), ("dynerf_default", 40100, 0.37), ("hypernerf_default", 5000, 1.0)])
-def test_deform_parity_16_gaussian_form_of_the_forward_kernel(cfg, n, t, monkeypatch):
-    """FDGS_D1_FORM=16: the forward kernel's 16-Gaussians-per-wave form (csrc/deform_fwd16.h: v_mfma_f32_16x16x4_f32, two waves per SIMD,
-    W0 / W1 read as packed operand streams) -- same oracle, same tolerances, forward AND the backward that consumes its saved activations
-    and ReLU bit masks; sizes with a partial last tile, a single tile, and the leftover-tile split of the persistent loop."""
-    monkeypatch.setenv("FDGS_D1_FORM", "16")
+@pytest.mark.parametrize("form", ["32", "17"])
+def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form, monkeypatch):
+    """The forms of the forward kernel that are NOT the default.  (Default, exercised by every other test here: FDGS_D1_FORM=16, the
+    16-Gaussians-per-wave form of csrc/deform_fwd16.h: v_mfma_f32_16x16x4_f32, two waves per SIMD, W0 / W1 read as packed operand streams.)
+    FDGS_D1_FORM=32: one wave = 32 Gaussians on v_mfma_f32_32x32x2_f32, one wave per SIMD (the default until round 4, and what the library
+    runs when the caller hands over no pack scratch) -- same oracle, same tolerances, forward AND the backward that consumes its saved
+    activations and ReLU bit masks; sizes with a partial last tile, a single tile, and the leftover-tile split of the persistent loop.
+    FDGS_D1_FORM=17: the same form with the operand streams handed through a per-workgroup LDS ring (one quarter of the vector-memory
+    requests per wave, one s_barrier per 16-KB period, the SH head's second layer in the stream)."""
+    monkeypatch.setenv("FDGS_D1_FORM", form)
     _parity(cfg, n, True, scalar_time=t)
 
 
