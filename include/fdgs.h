@@ -219,8 +219,10 @@ typedef struct fdgs_deform_out {
                          backward skip the gather and the recomputation of those layers (about 40 % of its MFMA work) */
     void* packed;     /* opt, fdgs_deform_pack_bytes() bytes of scratch: when given (and C % 16 == 0), the forward first re-orders W0 and the
                          heads' W1 into it as the operand streams of its matrix-core loops (contiguous 1-KB loads instead of 64 cache lines
-                         per request) and runs its 16-Gaussians-per-wave form, two waves per SIMD; NULL: the 32-Gaussian form on the
-                         row-major weights.  Same results up to summation order, same `saved` format. */
+                         per request) and runs its 16-Gaussians-per-wave form, two waves per SIMD -- the faster form inside a frame
+                          and what the Python host hands over by default; NULL: the 32-Gaussian form on the row-major
+                         weights.  Same results up to summation order, same `saved` format.  (Environment FDGS_D1_FORM=32 / 17 selects the
+                         32-Gaussian form / the LDS-ring variant of the 16-form for A/B runs.) */
 } fdgs_deform_out;
 
 int fdgs_deform_saved_bytes(const fdgs_deform_params* p, size_t* bytes);
