@@ -721,6 +721,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 }
 
 #include "deform_fwd16.h"
+#include "deform_fwd32g.h"
 
 // ------------------------------------------------------------------------------------------------ backward: prep
 // Per Gaussian: activation Jacobians -> packed pre-activation output gradients G[n][64]; direct (identity) paths.
@@ -2316,6 +2317,17 @@ struct Fwd16Launcher {
     }
 };
 template <int WT, int FCH>
+struct Fwd32gLauncher {      // (an experiment kept for A/B runs: instantiated for net_width 128 only, other widths run the 32-form)
+    static void go(hipStream_t s, int blocks, const DeformDev& d) {
+        if constexpr (WT == 4) {
+            if (d.packed) hipLaunchKernelGGL((deform_fwd32g_kernel<WT, FCH, true>), dim3(blocks), dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((deform_fwd32g_kernel<WT, FCH, false>), dim3(blocks), dim3(256), 0, s, d);
+        } else {
+            hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
+        }
+    }
+};
+template <int WT, int FCH>
 struct Fwd16RingLauncher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
         if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2, true>), dim3(blocks), dim3(256), 0, s, d);
@@ -2411,8 +2423,21 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         const int form_req = tunable("FDGS_D1_FORM", 16);
         const bool form16 = (form_req == 16 || form_req == 17) && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         const bool ring = form16 && form_req == 17;
+        const bool form32g = form_req == 33;      // the group-wise 32-Gaussian form (deform_fwd32g.h): two waves per SIMD, row-major weights
         d.packed = reinterpret_cast<const float*>(out->packed);
         d.skew = tunable("FDGS_D16_SKEW", 600);
+        if (form32g) {      // packed operand stream when the caller handed over scratch, W = 128 and FDGS_D32G_PACK != 0; else row-major
+            const bool pk = out->packed != nullptr && p->W == 128 && tunable("FDGS_D32G_PACK", 1) != 0;
+            if (pk) {
+                FDGS_TIMED("pack_weights", stream);
+                Pack32gArgs pa{};
+                for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
+                pa.W = p->W; pa.out = reinterpret_cast<float*>(out->packed);
+                hipLaunchKernelGGL(pack_weights32g_kernel, dim3(cdiv(FDGS_NUM_HEADS * 16 * (p->W / 32) * 64, 256)), dim3(256), 0, stream, pa);
+            } else {
+                d.packed = nullptr;
+            }
+        }
         if (form16) {
             FDGS_TIMED("pack_weights", stream);
             PackArgs pa{};
@@ -2422,7 +2447,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
             const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4 + (ring ? sh_ring_floats(p->W) / 4 : 0);
             hipLaunchKernelGGL(pack_weights16_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, pa);
         }
-        const int want = tunable("FDGS_D1_WGS", form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
+        const int want = tunable("FDGS_D1_WGS", (form16 || form32g) ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
         const int wg_tiles = form16 ? d.ntiles / 2 : d.ntiles / 4;           // (form 16: four 16-Gaussian tiles per workgroup)
         const int wgs = want > 0 && want < wg_tiles ? want : wg_tiles;
         d.prof = nullptr;
@@ -2432,7 +2457,8 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
         d.prof = prof_dev;
 #endif
-        rc = ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
+        rc = form32g ? dispatch_wf<Fwd32gLauncher>(p->W, d.F, stream, wgs, d)
+                  : ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
                   : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
 #ifdef FDGS_PROFILE_D1
         {

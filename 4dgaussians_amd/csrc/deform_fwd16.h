@@ -39,6 +39,9 @@
 #ifndef FDGS_D16_PD1
 #define FDGS_D16_PD1 2
 #endif
+#ifndef FDGS_D16_BURST
+#define FDGS_D16_BURST 0      // 1: the parked tile of saved activations leaves in two bursts of four pieces instead of one piece per stage
+#endif
 __device__ __forceinline__ f32x4 mm16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
@@ -658,7 +661,18 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
                     ring_barrier();
                 }
             } else {
+#if FDGS_D16_BURST
+            // the parked tile leaves in bursts of four pieces (stages 0 and 4 of group 0): four LDS reads, one wait, four stores -- a store
+            // per stage puts a store acknowledgement in front of every later operand wait (vmcnt counts loads and stores in issue order)
+            if (oh == 0) L1.run_group(0, hid, y, [&](int j) {
+                if ((j & 3) == 0 && j < NPIECE && pending_dst) {
+                    const v4f_ t0 = drain_read(j), t1 = drain_read(j + 1), t2 = drain_read(j + 2), t3 = drain_read(j + 3);
+                    drain_store(j, t0); drain_store(j + 1, t1); drain_store(j + 2, t2); drain_store(j + 3, t3);
+                }
+            });
+#else
             if (oh == 0) L1.run_group(0, hid, y, [&](int j) { drain_piece(j); });      // (the previous layer's parked tile leaves under group 0)
+#endif
             else L1.run_group(oh, hid, y, [&](int) {});
             }
             D1_TICK(3);

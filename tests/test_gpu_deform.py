@@ -61,7 +61,7 @@ def test_deform_forward_backward_parity(cfg, n, activate):
 
 @pytest.mark.parametrize("cfg,n,t", [("dnerf_bouncingballs", 1000, None), ("hypernerf_default", 257, None), ("dynerf_default", 1531, None),
                                      ("dynerf_default", 31, None), ("dynerf_default", 40100, 0.37), ("hypernerf_default", 5000, 1.0)])
-@pytest.mark.parametrize("form", ["32", "17"])
+@pytest.mark.parametrize("form", ["32", "17", "33"])
 def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form, monkeypatch):
     """The forms of the forward kernel that are NOT the default.  (Default, exercised by every other test here: FDGS_D1_FORM=16, the
     16-Gaussians-per-wave form of csrc/deform_fwd16.h: v_mfma_f32_16x16x4_f32, two waves per SIMD, W0 / W1 read as packed operand streams.)

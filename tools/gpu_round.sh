@@ -48,6 +48,12 @@ if [ -n "$PMC" ]; then
   cd $R
   python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq gpurun_out/${TAG}_pmc_sq.txt > /dev/null
   head -8 gpurun_out/${TAG}_pmc_sq.txt | cut -c1-230
+  # second set: where the vector-memory / LDS issue cycles and instruction counts of each kernel go (round 4: the forward kernel's idle MFMA cycles)
+  cd /tmp
+  timeout 240 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq2 -o pmc --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  cd $R
+  python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq2 gpurun_out/${TAG}_pmc_sq2.txt > /dev/null
+  head -6 gpurun_out/${TAG}_pmc_sq2.txt | cut -c1-230
   pmc_one $WL0 ""
 fi
 for WL in $EXTRA_WORKLOADS; do
@@ -76,5 +82,5 @@ if f:
 PY
 fi
 # drop the bulky raw traces from what travels back (summaries stay)
-rm -rf gpurun_out/${TAG}_prof*/ gpurun_out/${TAG}_pmc_FETCH_SIZE* gpurun_out/${TAG}_pmc_WRITE_SIZE* gpurun_out/${TAG}_pmc_sq/ 2>/dev/null
+rm -rf gpurun_out/${TAG}_prof*/ gpurun_out/${TAG}_pmc_FETCH_SIZE* gpurun_out/${TAG}_pmc_WRITE_SIZE* gpurun_out/${TAG}_pmc_sq/ gpurun_out/${TAG}_pmc_sq2/ 2>/dev/null
 exit 0
