@@ -2412,7 +2412,6 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) d.head_slot[hd] = p->head_on[hd] ? slot++ : 0;
     }
     {
-        FDGS_TIMED("deform_fwd", stream);
         d.ntiles = 4 * cdiv(p->N, 128);
         static int cus = 0;
         if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
@@ -2423,7 +2422,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         const int form_req = tunable("FDGS_D1_FORM", 16);
         const bool form16 = (form_req == 16 || form_req == 17) && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         const bool ring = form16 && form_req == 17;
-        const bool form32g = form_req == 33;      // the group-wise 32-Gaussian form (deform_fwd32g.h): two waves per SIMD, row-major weights
+        const bool form32g = form_req == 33;      // the group-wise 32-Gaussian form (deform_fwd32g.h, an experiment): two waves per SIMD
         d.packed = reinterpret_cast<const float*>(out->packed);
         d.skew = tunable("FDGS_D16_SKEW", 600);
         if (form32g) {      // packed operand stream when the caller handed over scratch, W = 128 and FDGS_D32G_PACK != 0; else row-major
@@ -2457,9 +2456,12 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
         d.prof = prof_dev;
 #endif
-        rc = form32g ? dispatch_wf<Fwd32gLauncher>(p->W, d.F, stream, wgs, d)
-                  : ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
-                  : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+        {
+            FDGS_TIMED("deform_fwd", stream);       // (the forward kernel alone; the operand-stream copy above is timed as "pack_weights")
+            rc = form32g ? dispatch_wf<Fwd32gLauncher>(p->W, d.F, stream, wgs, d)
+                      : ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
+                      : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+        }
 #ifdef FDGS_PROFILE_D1
         {
             static int reports = 0;

@@ -332,6 +332,10 @@ def run(args, make_step=None):
         roof["traffic"] = None
         if dom == "deform_bwd_data":
             roof["note"] = "saved activations: backward products only, live tiles only" if saved_on else "live tiles only"
+        if dom == "deform_fwd":
+            form = os.environ.get("FDGS_D1_FORM", "16")
+            roof["note"] = (f"forward kernel form {form} (16 = 16 Gaussians per wave, two waves per SIMD; DESIGN 3.1), timed alone; its operand-stream copy "
+                            f"pack_weights ({kern.get('pack_weights', {}).get('avg_ms', 0.0):.4f} ms per launch) is a separate kernel in kernels_ms_per_step")
         roof.update(pmc_traffic(dom, args.workload, lib_sha16(fdgs)))
     rooflines = [roofline_of(k) for k in sorted(kern, key=lambda k: -kern[k]["ms_per_step"]) if kern[k]["ms_per_step"] >= 0.05 * kernel_sum]
 
