@@ -80,3 +80,39 @@ def test_render_views_plumbing(fake):
     assert len(res) == 3
     sum(r["render"].sum() for r in res).backward()
     assert all(r["viewspace_points"].grad is not None for r in res) and pc._xyz.grad is not None
+
+
+def test_gradient_arena_layout_tiles_the_arena_without_overlap():
+    """deformation._arena_layout: every view starts 256-byte aligned, views do not overlap, the planes' strides are channels-last and the
+    per-Gaussian head ends where the zero-filled part begins; _collect caches per module and notices a replaced parameter."""
+    d = fdgs.deformation
+    planes = ((1, 16, 64, 64), (1, 16, 25, 64), (1, 16, 64, 25))
+    mlps = ((128, 32), (128,), (3, 128), (3,))
+    for combined in (True, False):
+        total, head, n_fixed, specs = d._arena_layout(1000, combined, planes, mlps)
+        assert n_fixed == (5 if combined else 6) and len(specs) == n_fixed + len(planes) + len(mlps)
+        arena = torch.zeros(total)
+        spans = []
+        for i, (shape, strides, off) in enumerate(specs):
+            assert off % 64 == 0
+            v = arena.as_strided(shape, strides, off)
+            n = v.numel()
+            spans.append((off, off + n))
+            v.fill_(float(i + 1))
+            if n_fixed <= i < n_fixed + len(planes):
+                assert v.is_contiguous(memory_format=torch.channels_last) and tuple(v.shape) == planes[i - n_fixed]
+            else:
+                assert v.is_contiguous()
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= total
+        assert head == specs[n_fixed][2]
+        for i, (shape, strides, off) in enumerate(specs):      # nobody wrote into anybody else's slice
+            assert bool((arena.as_strided(shape, strides, off) == float(i + 1)).all())
+    net = syn.SynthModel(50, "dynerf_default", seed=3)._deformation
+    a = d._collect(net)
+    b = d._collect(net)
+    assert a[0] is b[0] and a[1] is b[1]
+    seq = getattr(net.deformation_net, d.HEAD_NAMES[-1])
+    seq[3].bias = torch.nn.Parameter(seq[3].bias.detach().clone())
+    c = d._collect(net)
+    assert c[1] is not a[1] and c[1][-1] is seq[3].bias
