@@ -74,6 +74,16 @@ def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form, monkey
     _parity(cfg, n, True, scalar_time=t)
 
 
+@pytest.mark.parametrize("form", ["16", "17", "32", "33"])
+def test_deform_parity_leftover_tiles_split_by_head(form, monkeypatch):
+    """The persistent loop of the forward kernel deals the tiles left over after its last full round out BY HEAD (waves in forms 16 / 32 / 33,
+    whole workgroups in the ring form 17).  At test sizes that branch is only taken with a small grid: 5 000 Gaussians on 13 workgroups leave
+    8 of 320 tiles (form 16), 2 of 80 tile quads (form 17), 4 of 160 tiles (forms 32 / 33) for the split round."""
+    monkeypatch.setenv("FDGS_D1_FORM", form)
+    monkeypatch.setenv("FDGS_D1_WGS", "13")
+    _parity("dynerf_default", 5000, True, scalar_time=0.61)
+
+
 @pytest.mark.parametrize("cfg,n,t", [("dynerf_default", 2100, 0.37), ("hypernerf_default", 700, 1.0), ("dnerf_bouncingballs", 900, 0.0)])
 def test_deform_parity_one_frame_time(cfg, n, t):
     """render() hands ONE frame time to all Gaussians: the plane-gradient kernel then privatises the three time planes in
