@@ -90,6 +90,9 @@ SYMBOLS = {
     "fdgs_last_error": (c_char_p, []),
     "fdgs_abi_version": (c_int, []),
     "fdgs_device_arch": (c_int, [c_int, c_char_p, c_size_t]),
+    "fdgs_tuning_set": (c_int, [c_char_p, c_int]),
+    "fdgs_tuning_get": (c_int, [c_char_p, POINTER(c_int)]),
+    "fdgs_tuning_reset": (c_int, []),
     "fdgs_timing_enable": (c_int, [c_int]),
     "fdgs_timing_report": (c_int, [c_char_p, c_size_t, c_int]),
     "fdgs_geom_bytes": (c_int, [c_int, POINTER(c_size_t)]),
@@ -150,6 +153,35 @@ def lib():
 def check(rc):
     if rc != 0:
         raise FdgsError(f"libfdgs error {rc}: {lib().fdgs_last_error().decode(errors='replace')}")
+
+
+def tuning_set(name, value):
+    """Set one of the library's development knobs (include/fdgs.h: fdgs_tuning_set).  Process-global; set between frames."""
+    check(lib().fdgs_tuning_set(name.encode(), int(value)))
+
+
+def tuning_get(name):
+    v = c_int()
+    check(lib().fdgs_tuning_get(name.encode(), v))
+    return v.value
+
+
+class tuning:
+    """`with _lib.tuning(skip_dead=0, d1_form=32): ...` -- knobs set for the block, previous values restored after it (tests, bench A/B legs)."""
+
+    def __init__(self, **knobs):
+        self.knobs, self.old = knobs, {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.old[k] = tuning_get(k)
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def stream_ptr():

@@ -4,12 +4,41 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <strings.h>
 #include <vector>
 
 namespace fdgs {
 thread_local char g_err[512] = {0};
 
 bool g_timing_on = false;
+
+// knob table: name (the FDGS_<NAME> environment variable, also the fdgs_tuning_set key in either spelling), field, default
+namespace {
+struct KnobDesc { const char* name; int Tuning::*field; int dflt; };
+const KnobDesc kKnobs[] = {
+    {"D1_FORM", &Tuning::d1_form, 16}, {"D1_WGS", &Tuning::d1_wgs, -1}, {"D1_SPLIT", &Tuning::d1_split, 1}, {"SKIP_DEAD", &Tuning::skip_dead, 1},
+    {"D4_MFMA", &Tuning::d4_mfma, -1}, {"D4_ROWS_KB", &Tuning::d4_rows_kb, -1}, {"TILE_CULL", &Tuning::tile_cull, 1}, {"RBWD_PPL", &Tuning::rbwd_ppl, 4},
+};
+Tuning tuning_from_environment() {       // runs once, from the static initialiser below (library load)
+    Tuning t{};
+    for (const KnobDesc& k : kKnobs) {
+        char env[64];
+        snprintf(env, sizeof(env), "FDGS_%s", k.name);
+        const char* v = getenv(env);
+        t.*(k.field) = (v && *v) ? atoi(v) : k.dflt;
+    }
+    return t;
+}
+const KnobDesc* find_knob(const char* name) {
+    if (!name) return nullptr;
+    if (strncasecmp(name, "FDGS_", 5) == 0) name += 5;
+    for (const KnobDesc& k : kKnobs)
+        if (strcasecmp(name, k.name) == 0) return &k;
+    return nullptr;
+}
+}  // namespace
+static const Tuning g_tune_at_load = tuning_from_environment();
+Tuning g_tune = g_tune_at_load;
 namespace {
 struct TimingRec { const char* name; hipEvent_t e0, e1; };
 std::mutex g_tmu;
@@ -123,7 +152,24 @@ __global__ void __launch_bounds__(L1S_THREADS) l1_stats_kernel(size_t n, size_t 
 using namespace fdgs;
 
 extern "C" const char* fdgs_last_error(void) { return g_err; }
-extern "C" int fdgs_abi_version(void) { return 3; }
+extern "C" int fdgs_abi_version(void) { return 4; }
+
+extern "C" int fdgs_tuning_set(const char* name, int value) {
+    const KnobDesc* k = find_knob(name);
+    if (!k) return fail(FDGS_E_INVALID, "unknown tuning knob '%s'", name ? name : "(null)");
+    g_tune.*(k->field) = value;
+    return FDGS_OK;
+}
+extern "C" int fdgs_tuning_get(const char* name, int* value) {
+    const KnobDesc* k = find_knob(name);
+    if (!k || !value) return fail(FDGS_E_INVALID, "unknown tuning knob '%s'", name ? name : "(null)");
+    *value = g_tune.*(k->field);
+    return FDGS_OK;
+}
+extern "C" int fdgs_tuning_reset(void) {
+    g_tune = g_tune_at_load;      // (the environment as it was when the library was loaded)
+    return FDGS_OK;
+}
 
 extern "C" int fdgs_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(g_tmu);

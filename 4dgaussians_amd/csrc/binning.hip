@@ -474,7 +474,7 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     }
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
-    { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256), tunable("FDGS_EXPAND_SPLIT", 2)), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
+    { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256), 2), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
                        at<uint32_t>(geom, gl.total), il.gx,
                        at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2)); }

@@ -50,11 +50,20 @@ constexpr int TILE = FDGS_TILE;
 constexpr int TILE_PIX = TILE * TILE;  // 256 threads = 4 wave64 per tile
 constexpr int WAVE = 64;
 
-// integer tuning knob from the environment (development/diagnostics only; the defaults are the tuned values)
-inline int tunable(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+// ---- development / test knobs: ONE table (api.hip).  The environment is read ONCE, when the library is loaded; at run time a knob changes
+// only through fdgs_tuning_set() -- no C-ABI call reads the environment.  Everything else that used to be an FDGS_* variable is a constant
+// at its point of use (the tuned value; the sweeps are in profiles/r01b_tuning_sweep.txt).  Documented in INTEGRATION.md.
+struct Tuning {
+    int d1_form;     // FDGS_D1_FORM     16 (default: deform_fwd16_kernel where it applies) | 32 (deform_fwd_kernel)
+    int d1_wgs;      // FDGS_D1_WGS      workgroups of the forward kernel; -1 = two (form 16) / one (form 32) per CU, 0 = one per four tiles
+    int d1_split;    // FDGS_D1_SPLIT    1 = the leftover tiles of the persistent loop are split by head over the waves
+    int skip_dead;   // FDGS_SKIP_DEAD   1 = the deformation backward skips tiles without a gradient row (modes 0 / 2 of packed_rows_ready)
+    int d4_mfma;     // FDGS_D4_MFMA     -1 = the caller's order hint picks the plane-gradient kernel, 1 / 0 force the splat / the per-corner form
+    int d4_rows_kb;  // FDGS_D4_ROWS_KB  -1 = the time rows get all the LDS that is left; >= 0 caps it (tests: rows that do not fit)
+    int tile_cull;   // FDGS_TILE_CULL   1 = exact tile culling, 0 = the reference's rectangle lists
+    int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: 4 (default) | 2 | 0 = the 256-thread form
+};
+extern Tuning g_tune;
 
 // per-device host-side state (cached events, "function attribute already raised" flags) is indexed by the current device
 constexpr int FDGS_MAX_DEVICES = 64;

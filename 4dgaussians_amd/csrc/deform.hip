@@ -721,7 +721,6 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 }
 
 #include "deform_fwd16.h"
-#include "deform_fwd32g.h"
 
 // ------------------------------------------------------------------------------------------------ backward: prep
 // Per Gaussian: activation Jacobians -> packed pre-activation output gradients G[n][64]; direct (identity) paths.
@@ -2301,9 +2300,6 @@ static int dispatch_wf(int W, int F, hipStream_t stream, int blocks, const Arg& 
 #undef FDGS_CASE
     return fail(FDGS_E_INVALID, "%s", "unsupported (net_width, C*L) combination");
 }
-// floats of the SH head's stream in the ring form of deform_fwd16_kernel (pack_weights16_kernel, third segment): per output group the
-// group's W1 stages + four stages of its second-layer share
-static int sh_ring_floats(int W) { const int OT = W / 16, OH = OT / 4, HV = OT / 4; return OH * (4 * HV + 4) * 1024; }
 template <int WT, int FCH>
 struct FwdLauncher {
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
@@ -2311,26 +2307,10 @@ struct FwdLauncher {
     }
 };
 template <int WT, int FCH>
-struct Fwd16Launcher {
+struct Fwd16Launcher {      // (the caller only selects this form when FCH is even: C*L % 16 == 0)
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
         if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2>), dim3(blocks), dim3(256), 0, s, d);
-    }
-};
-template <int WT, int FCH>
-struct Fwd32gLauncher {      // (an experiment kept for A/B runs: instantiated for net_width 128 only, other widths run the 32-form)
-    static void go(hipStream_t s, int blocks, const DeformDev& d) {
-        if constexpr (WT == 4) {
-            if (d.packed) hipLaunchKernelGGL((deform_fwd32g_kernel<WT, FCH, true>), dim3(blocks), dim3(256), 0, s, d);
-            else hipLaunchKernelGGL((deform_fwd32g_kernel<WT, FCH, false>), dim3(blocks), dim3(256), 0, s, d);
-        } else {
-            hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
-        }
-    }
-};
-template <int WT, int FCH>
-struct Fwd16RingLauncher {
-    static void go(hipStream_t s, int blocks, const DeformDev& d) {
-        if constexpr ((FCH % 2) == 0) hipLaunchKernelGGL((deform_fwd16_kernel<2 * WT, FCH / 2, true>), dim3(blocks), dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((deform_fwd_kernel<WT, FCH>), dim3(blocks), dim3(256), 0, s, d);
     }
 };
 template <int WT, int FCH, bool SAVED>
@@ -2345,7 +2325,7 @@ static void launch_bwd_data(hipStream_t s, int max_blocks, const BwdDev& d) {
             per_cu = 1;
         resident = cus * per_cu;
     }
-    int blocks = tunable("FDGS_D2_WGS", resident);
+    int blocks = resident;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((deform_bwd_data_kernel<WT, FCH, SAVED>), dim3(blocks), dim3(256), 0, s, d);
@@ -2401,7 +2381,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
     if (p->N == 0) return FDGS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeformDev d;
-    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = tunable("FDGS_SMALL_HEADS", 1); d.split_tail = tunable("FDGS_D1_SPLIT", 1); d.sc = aabb_scale(p);
+    d.p = *p; d.out = *out; d.F = p->C * p->L; d.small_heads = 1; d.split_tail = g_tune.d1_split; d.sc = aabb_scale(p);
     {
         const SavedLayout sl = saved_layout(p);
         float* sv = reinterpret_cast<float*>(out->saved);
@@ -2418,35 +2398,19 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         // 16-Gaussian form (deform_fwd16.h): two workgroups per CU, needs whole float4 texel quarters per lane group (C % 16 == 0)
         // which form of the forward kernel: 16 (default where it applies: two waves per SIMD; in the frame, where the gather starts on cold
         // caches behind the previous frame's backward, it measured 5 - 7 % faster than the 32-form on every workload, profiles/r04_d1_forms.txt)
-        // | 32 | 17 (= 16 with the operand streams handed through an LDS ring; measured no faster)
-        const int form_req = tunable("FDGS_D1_FORM", 16);
-        const bool form16 = (form_req == 16 || form_req == 17) && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
-        const bool ring = form16 && form_req == 17;
-        const bool form32g = form_req == 33;      // the group-wise 32-Gaussian form (deform_fwd32g.h, an experiment): two waves per SIMD
+        // | 32 (also what runs when C*L is not a multiple of 16 or the caller hands over no pack scratch)
+        const bool form16 = g_tune.d1_form != 32 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         d.packed = reinterpret_cast<const float*>(out->packed);
-        d.skew = tunable("FDGS_D16_SKEW", 600);
-        if (form32g) {      // packed operand stream when the caller handed over scratch, W = 128 and FDGS_D32G_PACK != 0; else row-major
-            const bool pk = out->packed != nullptr && p->W == 128 && tunable("FDGS_D32G_PACK", 1) != 0;
-            if (pk) {
-                FDGS_TIMED("pack_weights", stream);
-                Pack32gArgs pa{};
-                for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
-                pa.W = p->W; pa.out = reinterpret_cast<float*>(out->packed);
-                hipLaunchKernelGGL(pack_weights32g_kernel, dim3(cdiv(FDGS_NUM_HEADS * 16 * (p->W / 32) * 64, 256)), dim3(256), 0, stream, pa);
-            } else {
-                d.packed = nullptr;
-            }
-        }
+        d.skew = 600;       // (s_memtime ticks; sweep 0 .. 24 k in profiles/r04_d1_forms.txt)
         if (form16) {
             FDGS_TIMED("pack_weights", stream);
             PackArgs pa{};
             pa.w0 = p->w0; pa.W = p->W; pa.F = d.F; pa.out = reinterpret_cast<float*>(out->packed);
             for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) { pa.w1[hd] = p->w1[hd]; pa.head_on[hd] = p->head_on[hd]; }
-            pa.w2_sh = p->w2[FDGS_HEAD_SHS]; pa.ring = ring ? 1 : 0;
-            const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4 + (ring ? sh_ring_floats(p->W) / 4 : 0);
+            const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4;
             hipLaunchKernelGGL(pack_weights16_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, pa);
         }
-        const int want = tunable("FDGS_D1_WGS", (form16 || form32g) ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
+        const int want = g_tune.d1_wgs >= 0 ? g_tune.d1_wgs : (form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
         const int wg_tiles = form16 ? d.ntiles / 2 : d.ntiles / 4;           // (form 16: four 16-Gaussian tiles per workgroup)
         const int wgs = want > 0 && want < wg_tiles ? want : wg_tiles;
         d.prof = nullptr;
@@ -2458,9 +2422,7 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
 #endif
         {
             FDGS_TIMED("deform_fwd", stream);       // (the forward kernel alone; the operand-stream copy above is timed as "pack_weights")
-            rc = form32g ? dispatch_wf<Fwd32gLauncher>(p->W, d.F, stream, wgs, d)
-                      : ring ? dispatch_wf<Fwd16RingLauncher>(p->W, d.F, stream, wgs, d)
-                      : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+            rc = form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
         }
 #ifdef FDGS_PROFILE_D1
         {
@@ -2489,7 +2451,7 @@ extern "C" int fdgs_deform_pack_bytes(const fdgs_deform_params* p, size_t* bytes
     int rc = validate_deform(p);
     if (rc) return rc;
     FDGS_REQUIRE(bytes, "bytes is NULL");
-    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W + (size_t)sh_ring_floats(p->W)) * sizeof(float);
+    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W) * sizeof(float);
     return FDGS_OK;
 }
 
@@ -2555,17 +2517,16 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     }
     if (nh == 0) return FDGS_OK;  // no head active: the deformation is the identity
     // plane-gradient kernel choice and its chunk size (the chunk list is built for it)
-    const int d4_env = tunable("FDGS_D4_MFMA", -1);
+    const int d4_env = g_tune.d4_mfma;
     const bool use_mfma = !p->time && (d4_env >= 0 ? d4_env != 0 : g->spatially_ordered != 0);
-    const int nwv = tunable("FDGS_D4_WAVES", 8) == 4 ? 4 : 8;
-    const int Gc = (nwv == 8 ? 2048 : 1024) / p->C;
+    const int Gc = 2048 / p->C;      // Gaussians per chunk of the splat
     {
         // tiles with a non-zero gradient row -> lists.  packed_rows_ready = 1: rows without flags -- every tile is live and the kernel writes
         // the flags (all ones); 3: the rows of dead tiles were never written -- skipping is not a choice then, whatever the A/B knob says
         CompactArgs ca{};
         ca.flags = s.tile_live; ca.live = s.live; ca.chunks = s.chunks; ca.counters = s.counters; ca.G = s.G;
         ca.ntiles = (int)(Np / 32); ca.tpc = Gc / 32;
-        ca.skip = g->packed_rows_ready == 3 ? 1 : ((tunable("FDGS_SKIP_DEAD", 1) != 0 && g->packed_rows_ready != 1) ? 1 : 0);
+        ca.skip = g->packed_rows_ready == 3 ? 1 : ((g_tune.skip_dead != 0 && g->packed_rows_ready != 1) ? 1 : 0);
         { FDGS_TIMED("tile_compact", stream); hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, stream, ca); }
         FDGS_LAUNCH_CHECK("tile_compact", 0, stream);
     }
@@ -2573,11 +2534,11 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         if (p->head_on[hd]) FDGS_REQUIRE(g->d_w1[hd] && g->d_b1[hd] && g->d_w2[hd] && g->d_b2[hd], "head gradient buffer missing");
     FDGS_REQUIRE(g->d_w0 && g->d_b0, "trunk gradient buffer missing");
     BwdDev bd;
-    bd.p = *p; bd.sc = aabb_scale(p); bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = tunable("FDGS_SMALL_HEADS", 1);
+    bd.p = *p; bd.sc = aabb_scale(p); bd.s = s; bd.F = (int)F; bd.ntiles = (int)(Np / 32); bd.small_heads = 1;
     const float* X_rh = s.RH;      // operands of the weight-gradient GEMMs: recomputed into scratch, or saved by the forward
     const float* X_feat = s.FEAT;
     bd.sv_rh = bd.sv_h1 = nullptr; bd.sv_hmask = nullptr;
-    if (g->saved && tunable("FDGS_USE_SAVED", 1)) {
+    if (g->saved) {
         const SavedLayout sl = saved_layout(p);
         const float* sv = reinterpret_cast<const float*>(g->saved);
         bd.sv_rh = sv + sl.rh; bd.sv_h1 = sv + sl.h1; bd.sv_hmask = reinterpret_cast<const uint32_t*>(sv + sl.hmask);
@@ -2643,12 +2604,12 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int total_wgs = tunable("FDGS_WGRAD_WGS", cus);
+        const int total_wgs = cus;
         int work[FDGS_NUM_HEADS + 1], total_work = 0;
         // cost model: MFMAs per k-step; the narrow trunk product (dword loads, only CT MFMAs per load pair, deep ring) is
         // memory-latency rather than MFMA bound: it costs about twice its MFMA count (sweep: 0.53 / 0.44 / 0.46 / 0.48 ms at
         // factor 1 / 2 / 3 / 4)
-        const int trunk_factor = tunable("FDGS_WGRAD_TRUNK", 2);
+        const int trunk_factor = 2;
         for (int j = 0; j < nj; j++) {
             work[j] = (wa.job[j].ncols + 31) / 32;
             if (wa.job[j].ncols != (int)W) work[j] *= trunk_factor;
@@ -2681,18 +2642,16 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
         // matrix-core splat (default whenever one frame time is shared by all Gaussians, i.e. on the render() path): the
         // fixed LDS part is the dv tile, coordinates, descriptors; the time rows get what is left of the 160 KB
         // FDGS_D4_MFMA = 1 / 0 forces a kernel (A/B, tests); otherwise the caller's order hint decides
-        // workgroup shape of the splat: 8 waves, one workgroup per CU (default); FDGS_D4_WAVES=4 selects 4-wave workgroups with half
-        // the chunk, two per CU where the LDS allows -- measured equal on BASELINE config 4 (0.331 vs 0.322 ms: overlapping one
-        // workgroup's sampling with the other's matrix-core phase buys what the smaller chunks lose in merging), kept for A/B
-        auto fixed_floats_of = [&](int nwv) { const int Gv = (nwv == 8 ? 2048 : 1024) / p->C; return 6 * Gv * p->C + 3 * Gv + 13 * Gv + 3 * Gv + (96 + 9 * Gv) + 64; };
-        const int fixed_floats = fixed_floats_of(nwv);
+        // workgroup shape of the splat: 8 waves, one workgroup per CU (4-wave workgroups with half the chunk, two per CU, measured equal on
+        // BASELINE config 4 -- 0.331 vs 0.322 ms -- and were dropped)
+        const int fixed_floats = 6 * Gc * p->C + 3 * Gc + 13 * Gc + 3 * Gc + (96 + 9 * Gc) + 64;
         // LDS privatisation of the time planes (one frame time for all Gaussians): greedy by level while the tiles fit
         // bytes per workgroup: up to 128 KB (one 512-thread workgroup per CU then; the un-privatised alternative, float
         // atomics on ~128 hot lines, is 4x slower than scattered atomics)
         int lds_budget = use_mfma ? 160 * 1024 - fixed_floats * 4
-                                  : (tunable("FDGS_PG_LDS", 1) ? tunable("FDGS_PG_LDS_KB", 128) * 1024 : 0);
-        if (use_mfma && tunable("FDGS_D4_ROWS_KB", -1) >= 0 && tunable("FDGS_D4_ROWS_KB", -1) * 1024 < lds_budget)
-            lds_budget = tunable("FDGS_D4_ROWS_KB", -1) * 1024;     // (tests: time rows that do not fit take the global-atomic path)
+                                  : 128 * 1024;
+        if (use_mfma && g_tune.d4_rows_kb >= 0 && g_tune.d4_rows_kb * 1024 < lds_budget)
+            lds_budget = g_tune.d4_rows_kb * 1024;     // (tests: time rows that do not fit take the global-atomic path)
         int used = 0;
         for (int l = 0; l < FDGS_MAX_LEVELS; l++)
             for (int sl = 0; sl < 3; sl++) ga.lds_off[l][sl] = -1;
@@ -2728,23 +2687,19 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             ma.off_dq = o; o += 3 * Gc;
             ma.off_org = o; o += 96 + 9 * Gc;
             const size_t lds_bytes = (size_t)o * 4;
-            int blocks = tunable("FDGS_PGM_WGS", nwv == 4 ? 512 : 256);
+            int blocks = 256;
             if (blocks > nchunks_max) blocks = nchunks_max;
-            const void* fn = p->C == 16 ? (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 4>)
-                                                     : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 8>))
-                                        : (nwv == 4 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 4>)
-                                                     : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 8>));
-            static bool raised[FDGS_MAX_DEVICES][4] = {};      // (a function attribute is set per device)
-            bool& r_ = raised[current_device_slot()][(p->C == 16 ? 0 : 2) + (nwv == 4 ? 0 : 1)];
+            const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 8>)
+                                        : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 8>);
+            static bool raised[FDGS_MAX_DEVICES][2] = {};      // (a function attribute is set per device)
+            bool& r_ = raised[current_device_slot()][p->C == 16 ? 0 : 1];
             if (!r_) {
                 FDGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 r_ = true;
             }
             {
                 FDGS_TIMED("deform_plane_grad", stream);
-                if (p->C == 16 && nwv == 4) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16, 4>), dim3(blocks), dim3(256), lds_bytes, stream, ma);
-                else if (p->C == 16) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16, 8>), dim3(blocks), dim3(512), lds_bytes, stream, ma);
-                else if (nwv == 4) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32, 4>), dim3(blocks), dim3(256), lds_bytes, stream, ma);
+                if (p->C == 16) hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<16, 8>), dim3(blocks), dim3(512), lds_bytes, stream, ma);
                 else hipLaunchKernelGGL((deform_plane_grad_mfma_kernel<32, 8>), dim3(blocks), dim3(512), lds_bytes, stream, ma);
             }
             FDGS_LAUNCH_CHECK("deform_plane_grad", 0, stream);
@@ -2770,7 +2725,7 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             return FDGS_OK;
         }
         const int gpb = (PG_THREADS / 64) * (64 / (2 * p->C));       // Gaussians per workgroup iteration
-        int nwg = tunable("FDGS_PG_WGS", 512);                        // ~2 workgroups per CU
+        int nwg = 512;                                                // ~2 workgroups per CU
         int per_block = cdiv(p->N, nwg);
         per_block = cdiv(per_block, gpb) * gpb;
         if (per_block < gpb) per_block = gpb;

@@ -19,7 +19,11 @@
 // left: a hidden-layer product takes 11.4 k cycles alone even with every operand request an L1 hit (8.2 k of MFMA issue: ~200 cycles per
 // 16-MFMA stage that are not the stream's latency), 13.3 k with the real stream at 2 stages of requests in flight, and a third / fourth
 // stage in flight does not fit 256 registers without spills (each A register feeds ONE 32-cycle MFMA here, against one 64-cycle MFMA in the
-// 32-form: twice the registers for the same latency cover).  Default stays the 32-form; FDGS_D1_FORM=16 selects this one.
+// 32-form: twice the registers for the same latency cover).  MEASURED IN THE FRAME (where the kernel starts on cold planes behind the previous
+// frame's backward) this form is 5 - 7 % faster on every workload and is the DEFAULT; the 32-form (deform_fwd_kernel) runs when
+// C*L is not a multiple of 16 or the caller hands over no pack scratch (fdgs_tuning "d1_form" = 32 forces it).  Two further forms
+// built on it (operand streams through an LDS ring; a group-wise 32-Gaussian form) measured no faster and live as a patch under
+// tools/_experiments/deform_d1_forms_17_33.diff.txt.
 //
 // Lane = (n, q): n = lane & 15 the Gaussian, q = lane >> 4.  MFMA 16x16x4: A[i][k] in lane i + 16k, B[k][n] in lane n + 16k,
 // D[row][n] in lane n + 16q register r with row = 4q + r.
@@ -30,17 +34,8 @@
 // corner), k-step (u, c).  tools/mfma_layout_model.py (check16) replays all of it lane by lane against plain matrix algebra
 // (tests/test_mfma_layouts.py).
 
-#ifndef FDGS_D16_EAGER
-#define FDGS_D16_EAGER 1      // 1: a head's epilogue inputs are requested in front of its hidden-layer product; 0: in the epilogue
-#endif
-#ifndef FDGS_D16_SYNC
-#define FDGS_D16_SYNC 1       // workgroup barriers per hidden-layer product (0 = none): keeps the four waves of a workgroup on the same
-#endif                         // 16 KB of a weight stream, so that one of them pulls a line from L2 and the others hit it in the CU's L1
 #ifndef FDGS_D16_PD1
-#define FDGS_D16_PD1 2
-#endif
-#ifndef FDGS_D16_BURST
-#define FDGS_D16_BURST 0      // 1: the parked tile of saved activations leaves in two bursts of four pieces instead of one piece per stage
+#define FDGS_D16_PD1 2        // operand-request stages in flight per hidden-layer product (3 / 4 do not fit 256 registers without spills)
 #endif
 __device__ __forceinline__ f32x4 mm16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -93,11 +88,7 @@ struct Dense16 {
     __device__ __forceinline__ void fetch(int s, float4* dst) const {
         if constexpr (PACKED) {
 #pragma unroll
-#ifdef FDGS_D16_DEBUG_SAMESTAGE      // (wrong results on purpose: every stage reads the first 4 KB -- is the stream's latency what the loop waits for?)
-            for (int o = 0; o < OG; o++) dst[o] = *reinterpret_cast<const float4*>(base + (ro[0] + (uint32_t)(((s & 1) * OG + o) * 1024)));
-#else
             for (int o = 0; o < OG; o++) dst[o] = *reinterpret_cast<const float4*>(base + (ro[0] + (uint32_t)((s * OG + o) * 1024)));
-#endif
         } else {
             const int hf = s % HV, r = (s / HV) % 4, oh = s / (4 * HV);
 #pragma unroll
@@ -189,30 +180,12 @@ struct Trunk16 {
 // W0 and the heads' W1 re-ordered into the operand streams of Trunk16 / Dense16 (one float4 per thread; 366 KB at net_width 128: a few
 // microseconds, run by fdgs_deform_fwd in front of the forward kernel -- the weights change every optimizer step).
 // Packed buffer: [W0: F * W floats][head 0 W1: W * W floats] ... [head 4].
-// Ring form (deform_fwd16_kernel<.., RING = true>): a THIRD segment follows -- the SH head's stream as that form consumes it, per output
-// group oh: [W1 stages of the group (NSG)] [second-layer share of the group: 4 stages r = 0 .. 3 of pieces ot = 0 .. 2 (piece 3 = zeros),
-// lane (n, q) = W2[min(16 ot + n, k - 1)][KT (4q + r) + 4 oh .. + 3]], so that the whole head is one run of 4-stage periods.
-struct PackArgs { const float* w0; const float* w1[FDGS_NUM_HEADS]; int head_on[FDGS_NUM_HEADS]; int W, F; float* out; const float* w2_sh; int ring; };
+struct PackArgs { const float* w0; const float* w1[FDGS_NUM_HEADS]; int head_on[FDGS_NUM_HEADS]; int W, F; float* out; };
 __global__ void __launch_bounds__(256) pack_weights16_kernel(PackArgs a) {
     const int W = a.W, F = a.F, OT = W / 16, OG = 4, OH = OT / OG, KT = W / 16, HV = KT / 4;
     const int n4_trunk = F * W / 4, n4_head = W * W / 4;
     int e = blockIdx.x * 256 + threadIdx.x;
-    const int n4_base = n4_trunk + FDGS_NUM_HEADS * n4_head;
-    if (e >= n4_base) {
-        const int NSG = 4 * HV, e2 = e - n4_base;
-        if (!a.ring || !a.head_on[FDGS_HEAD_SHS] || e2 >= OH * (NSG + 4) * 256) return;
-        const int lane = e2 & 63, o = (e2 >> 6) & 3, s = e2 >> 8, gi = s / (NSG + 4), js = s - gi * (NSG + 4), n = lane & 15, q = lane >> 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (js < NSG) {
-            const int hf = js % HV, r = js / HV;
-            v = *reinterpret_cast<const float4*>(a.w1[FDGS_HEAD_SHS] + (size_t)(OT * n + OG * gi + o) * W + KT * (4 * q + r) + 4 * hf);
-        } else if (o < 3) {
-            const int r = js - NSG, k = head_k(FDGS_HEAD_SHS), row2 = (16 * o + n) < k ? (16 * o + n) : k - 1;
-            v = *reinterpret_cast<const float4*>(a.w2_sh + (size_t)row2 * W + KT * (4 * q + r) + 4 * gi);
-        }
-        reinterpret_cast<float4*>(a.out)[e] = v;
-        return;
-    }
+    if (e >= n4_trunk + FDGS_NUM_HEADS * n4_head) return;
     const float* src;
     int row, col, ld;
     if (e < n4_trunk) {
@@ -290,15 +263,7 @@ __device__ __forceinline__ void park16(float* tile, int stride, const f32x4* x, 
                 make_float4(x[4 * hf][r], x[4 * hf + 1][r], x[4 * hf + 2][r], x[4 * hf + 3][r]);
 }
 
-// RING (round 4, FDGS_D1_FORM=17): the operand streams reach the MFMAs through a per-workgroup LDS ring instead of per-wave global
-// loads.  tools/mfma_chain_probe.hip: a wave that issues ONE global_load_dwordx4 per four 32x32x2 MFMAs loses 13 % of the pipe alone and
-// 29 % with a second wave on the SIMD -- whether or not anything waits for the data (the issue of a vector-memory instruction is what
-// costs) -- while the same stream read with ds_read_b128 runs at 0.96 / 0.97.  The four waves of a workgroup consume the SAME packed
-// stream, so each wave fetches a quarter of it (one 4-KB stage per 16-KB period, staged in 16 registers, written to the other half of
-// the ring) and reads all of it from LDS: a quarter of the vector-memory instructions, one s_barrier per period.  The SH head's
-// second-layer weights ride in the same stream (pack_weights16_kernel, third segment); tiles are dealt to workgroups, not waves.
-typedef float v4f_ __attribute__((ext_vector_type(4)));
-template <int WT16, int FU, bool RING = false>
+template <int WT16, int FU>
 __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     constexpr int W = 16 * WT16, KT = WT16, OT = WT16;
     constexpr int PD1 = FDGS_D16_PD1;
@@ -308,16 +273,14 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     constexpr int NPIECE = W / 16;        // 1-KB pieces of a parked [16][W] tile (64 float4 each)
     static_assert(NPIECE <= NSG, "a parked tile is drained within the first output group of the next layer (whose results then park over it)");
     const fdgs_deform_params& p = d.p;
-    constexpr int W2ROWS = RING ? 11 : 59;          // (ring form: the SH head's 48 rows come with the stream)
-    constexpr int HALF = 4 * 1024;                  // floats of a ring half: one period = four 4-KB stages
-    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * LDW + W2ROWS * LDW + FDGS_NUM_HEADS * W + (RING ? 2 * HALF : 0)];
+    constexpr int W2ROWS = 59;                      // second-layer rows of the five heads (3 + 3 + 4 + 1 + 48)
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * LDW + W2ROWS * LDW + FDGS_NUM_HEADS * W];
     float* my_tile = lds + (threadIdx.x >> 6) * 16 * LDW;
     float* w2lds = lds + 4 * 16 * LDW;
     float* b1lds = w2lds + W2ROWS * LDW;        // the heads' first-layer biases (added with the ReLU, in IL16 order: two ds_read_b128 per register row)
-    float* ring = b1lds + FDGS_NUM_HEADS * W;
     for (int i = threadIdx.x; i < FDGS_NUM_HEADS * W; i += 256) b1lds[i] = p.head_on[i / W] ? p.b1[i / W][i % W] : 0.f;
     for (int hd_ = 0; hd_ < FDGS_NUM_HEADS; hd_++) {
-        if (!p.head_on[hd_] || (RING && hd_ == FDGS_HEAD_SHS)) continue;
+        if (!p.head_on[hd_]) continue;
         const int k_ = head_k(hd_), r0_ = head_row0(hd_);
         for (int i = threadIdx.x; i < k_ * (W / 4); i += 256) {
             const int r = i / (W / 4), c4 = i - r * (W / 4);
@@ -336,13 +299,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     }
 #ifdef FDGS_PROFILE_D1
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pw[2] = {0, 0};      // ring form: cycles inside the commit's vmcnt(0) and inside s_barrier (parts of the phases above)
-#define D1_WAITED(i, t0_) pw[i] += __builtin_amdgcn_s_memtime() - (t0_)
-#define D1_NOW() __builtin_amdgcn_s_memtime()
     unsigned long long pt = __builtin_amdgcn_s_memtime();
-#else
-#define D1_WAITED(i, t0_) do { } while (0)
-#define D1_NOW() 0ull
 #endif
     unsigned all_heads = 0u;
     int nh = 0;
@@ -350,54 +307,11 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     for (int i = 0; i < FDGS_NUM_HEADS; i++) if (p.head_on[i]) { all_heads |= 1u << i; nh++; }
     // persistent loop over 16-Gaussian tiles; the tiles left over after the last full round are dealt out by head (as in the 32-form)
     const int ntiles = d.ntiles * 2;
-    // RING: the unit of work is a QUAD of tiles per workgroup (its four waves walk the same stream in step); ntiles is a multiple of 8
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = RING ? ntiles / 4 : ntiles;
-    const int nwaves = RING ? (int)gridDim.x : (int)gridDim.x * 4, wave_id = RING ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
+    const int nunits = ntiles;
+    const int nwaves = (int)gridDim.x * 4, wave_id = (int)blockIdx.x * 4 + wv;
     const int full_rounds = nunits / nwaves, rem = nunits - full_rounds * nwaves;
     const bool split = d.split_tail != 0 && nh > 1 && rem > 0 && rem * nh <= nwaves;
-    // ---- ring state (RING only).  `cur` = half that holds the period about to be consumed; stg = this wave's stage of the next period
-    int cur = 0;
-    // (the requests are inline assembly so that they are issued HERE and waited for THERE; the compiler does not know that their results
-    // arrive late, so every request site must reach its commit in straight-line code -- no branch whose join would copy the four
-    // registers before the data are in them: every wave always requests "its" stage, also of a period with fewer than four stages (it
-    // then reads what follows in the packed buffer and fills a slot nobody reads).  tools/isa_scan.py --ring checks the ISA for such copies.)
-    v4f_ stg[4];
-    const float* const lane_src = d.packed + (size_t)wv * 1024 + (size_t)(threadIdx.x & 63) * 4;
-    auto ring_issue = [&](size_t period_off /* floats from d.packed, wave-uniform */) {
-        const float* ptr = lane_src + period_off;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
-                     : "=&v"(stg[0]), "=&v"(stg[1]), "=&v"(stg[2]), "=&v"(stg[3]) : "v"(ptr));
-    };
-    auto ring_commit = [&](int half) {
-        [[maybe_unused]] const unsigned long long tw_ = D1_NOW();
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]));
-        D1_WAITED(0, tw_);
-        float* dst = ring + half * HALF + wv * 1024 + (threadIdx.x & 63) * 4;
-#pragma unroll
-        for (int o = 0; o < 4; o++) *reinterpret_cast<v4f_*>(dst + o * 256) = stg[o];
-    };
-    auto ring_barrier = [&]() {
-        [[maybe_unused]] const unsigned long long tw_ = D1_NOW();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        D1_WAITED(1, tw_);
-        cur ^= 1;
-    };
-    auto ring_read = [&](int k, float4* dst) {      // stage k of the current period: one float4 per output tile of the group
-        const float* src = ring + cur * HALF + k * 1024 + (threadIdx.x & 63) * 4;
-#pragma unroll
-        for (int o = 0; o < 4; o++) dst[o] = *reinterpret_cast<const float4*>(src + o * 256);
-    };
-    constexpr int NS_T = FU * (OT / 4), PT = NS_T % 4 == 0 ? 4 : NS_T % 2 == 0 ? 2 : 1;      // trunk: stages, stages per period
-    constexpr size_t OFF_W1 = (size_t)FU * 16 * W;                                          // floats: [W0][W1 x 5][SH ring stream]
-    constexpr size_t OFF_SHR = OFF_W1 + (size_t)FDGS_NUM_HEADS * W * W;
-    auto stream_off = [&](int hd_) -> size_t { return hd_ >= FDGS_NUM_HEADS ? (size_t)0 : hd_ == FDGS_HEAD_SHS ? OFF_SHR : OFF_W1 + (size_t)hd_ * W * W; };
-    if (RING) {       // the first tile's first trunk period
-        ring_issue(0);
-        ring_commit(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
     for (int it = 0; it <= full_rounds; it++) {
     int tile = it * nwaves + wave_id;
     unsigned head_mask = all_heads;
@@ -414,7 +328,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
             break;
         }
     }
-    if (RING) tile = 4 * tile + wv;
     int n = n0, q = q0;
     asm volatile("" : "+v"(n), "+v"(q));   // keeps the per-layer weight addresses from being hoisted out of the tile loop
     const size_t tile_n0 = (size_t)tile * 16;
@@ -429,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     asm volatile("" : "+v"(lane_));
     Trunk16<FU, OT, 2> T0;
     T0.setup(d.packed, p.b0, n, q, lane_);
-    if (!RING) T0.preload();         // (in flight under the gather; ring form: the trunk's period already sits in the ring)
+    T0.preload();                    // (in flight under the gather)
     D1_TICK(0);
     float4 feat[FU];
 #pragma unroll
@@ -451,40 +364,14 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     int hd = __builtin_amdgcn_readfirstlane(next_head_m(head_mask, -1));     // (wave-uniform: scalar base addresses for the streams)
     Dense16<KT, OT, true, PD1, true> L1;
     const float* packed_w1 = d.packed + (size_t)d.F * W;
-    if (!RING && hd < FDGS_NUM_HEADS) { L1.setup_packed(packed_w1 + (size_t)hd * W * W, lane_); L1.preload(); }
+    if (hd < FDGS_NUM_HEADS) { L1.setup_packed(packed_w1 + (size_t)hd * W * W, lane_); L1.preload(); }
     const size_t g_row = (size_t)g_raw;     // saved rows are indexed by the un-clamped Gaussian slot (< Npad)
     if (d.sv_feat && primary) {
 #pragma unroll
         for (int u = 0; u < FU; u++) *reinterpret_cast<float4*>(d.sv_feat + g_row * d.F + 16 * u + 4 * q) = feat[u];
     }
     f32x4 hid[WT16];
-    if constexpr (!RING) {
-        T0.run(feat, hid);
-    } else {
-        constexpr int OHT = OT / 4, NPT = NS_T / PT;
-#pragma unroll
-        for (int ot = 0; ot < OT; ot++) hid[ot] = mm16(T0.bq == 0 ? T0.bv[ot] : 0.f, 1.0f, zero4());
-#pragma unroll
-        for (int tp = 0; tp < NPT; tp++) {
-            // the wave's stage of the NEXT period: the next trunk period, then the first head's (no head on: the next tile's trunk)
-            ring_issue(tp + 1 < NPT ? (size_t)(tp + 1) * PT * 1024 : stream_off(hd));
-            float4 a[2][4];
-            ring_read(0, a[0]);
-#pragma unroll
-            for (int jj = 0; jj < PT; jj++) {
-                const int st = tp * PT + jj, oh = st % OHT, u = st / OHT;
-                if (jj + 1 < PT) ring_read(jj + 1, a[(jj + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-#pragma unroll
-                    for (int o = 0; o < 4; o++) hid[4 * oh + o] = mm16(f4c(a[jj & 1][o], c), f4c(feat[u], c), hid[4 * oh + o]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            ring_commit(cur ^ 1);
-            ring_barrier();
-        }
-    }
+    T0.run(feat, hid);
 #pragma unroll
     for (int t = 0; t < WT16; t++)
 #pragma unroll
@@ -502,13 +389,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
             reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * LDW + 4 * c4);
         }
     };
-    // (tried and dropped: the drain in two halves a stage apart -- piece j read behind stage j's MFMAs, stored behind stage j + 1's, so that
-    // the LDS round trip of "read, wait, store" does not sit in the open: 0.645 against 0.635 ms in the frame, same job)
-    auto drain_read = [&](int j) -> v4f_ {
-        const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
-        return *reinterpret_cast<const v4f_*>(my_tile + row * LDW + 4 * c4);
-    };
-    auto drain_store = [&](int j, v4f_ v) { reinterpret_cast<v4f_*>(pending_dst)[j * 64 + lane] = v; };
     if (d.sv_rh && primary) {
         park(hid, d.sv_rh + tile_n0 * W);
         if (d.sv_hmask) {
@@ -602,7 +482,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     while (hd < FDGS_NUM_HEADS) {
         const int k = head_k(hd);
         const float* w2h = w2lds + head_row0(hd) * LDW;
-        if (FDGS_D16_EAGER) request_inputs(hd);
+        request_inputs(hd);
         const int row2 = (lane & 3) < k ? (lane & 3) : k - 1;
         const float bias2 = k <= 4 ? p.b2[hd][row2] : 0.f;
         const float* wr = w2h + row2 * LDW + KT * 4 * q;                 // k <= 4: A-lane 4b + i = W2[i][features of lane group q]
@@ -614,67 +494,12 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
         // second-layer accumulators, carried over the output groups of the hidden layer (each group = 4 of its KT k-tiles)
         f32x4 acc4[4] = {zero4(), zero4(), zero4(), zero4()};
         f32x4 osh[3] = {zero4(), zero4(), zero4()};
-        // ring form: this head's stream = OH groups of gper periods (HV of W1, + 1 of the SH head's W2 share); `nxt` picks what follows it
         const int nxt_r = __builtin_amdgcn_readfirstlane(next_head_m(head_mask, hd));
-        const int gper = L1T::HV + (k > 4 ? 1 : 0);
-        const size_t hoff = stream_off(hd);
-        const size_t after_head = stream_off(nxt_r);
-        auto issue_after = [&](int pi) {       // the period after period `pi` of this head
-            ring_issue(pi + 1 < OH * gper ? hoff + (size_t)(pi + 1) * HALF : after_head);
-        };
 #pragma unroll
         for (int oh = 0; oh < OH; oh++) {
             f32x4 y[OG];
-            if constexpr (RING) {
-#pragma unroll
-                for (int o = 0; o < OG; o++) y[o] = zero4();
-#pragma unroll
-                for (int pp = 0; pp < L1T::HV; pp++) {
-                    // the previous layer's parked tile leaves under group 0: its stores go out IN FRONT of the period's stream requests, so
-                    // that the vmcnt(0) of the commit (a whole period later) waits for nothing younger than the requests
-                    static_assert(NPIECE % L1T::HV == 0, "pieces per period");
-                    if (oh == 0 && pending_dst) {      // (all reads, one wait, all stores)
-                        constexpr int NPP = NPIECE / L1T::HV;
-                        v4f_ dp[NPP];
-#pragma unroll
-                        for (int jp = 0; jp < NPP; jp++) dp[jp] = drain_read(pp * NPP + jp);
-#pragma unroll
-                        for (int jp = 0; jp < NPP; jp++) asm volatile("" : "+v"(dp[jp]));
-#pragma unroll
-                        for (int jp = 0; jp < NPP; jp++) drain_store(pp * NPP + jp, dp[jp]);
-                    }
-                    issue_after(oh * gper + pp);
-                    float4 a[2][4];
-                    ring_read(0, a[0]);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int j = pp * 4 + jj, hf = j % L1T::HV, r = j / L1T::HV;
-                        if (jj < 3) ring_read(jj + 1, a[(jj + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < 4; c++)
-#pragma unroll
-                            for (int o = 0; o < OG; o++) y[o] = mm16(f4c(a[jj & 1][o], c), hid[4 * hf + c][r], y[o]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    ring_commit(cur ^ 1);
-                    ring_barrier();
-                }
-            } else {
-#if FDGS_D16_BURST
-            // the parked tile leaves in bursts of four pieces (stages 0 and 4 of group 0): four LDS reads, one wait, four stores -- a store
-            // per stage puts a store acknowledgement in front of every later operand wait (vmcnt counts loads and stores in issue order)
-            if (oh == 0) L1.run_group(0, hid, y, [&](int j) {
-                if ((j & 3) == 0 && j < NPIECE && pending_dst) {
-                    const v4f_ t0 = drain_read(j), t1 = drain_read(j + 1), t2 = drain_read(j + 2), t3 = drain_read(j + 3);
-                    drain_store(j, t0); drain_store(j + 1, t1); drain_store(j + 2, t2); drain_store(j + 3, t3);
-                }
-            });
-#else
             if (oh == 0) L1.run_group(0, hid, y, [&](int j) { drain_piece(j); });      // (the previous layer's parked tile leaves under group 0)
-#endif
             else L1.run_group(oh, hid, y, [&](int) {});
-            }
             D1_TICK(3);
             // bias + ReLU: register r of k-tile t = 4 oh + c holds feature KT (4q + r) + 4 oh + c
 #pragma unroll
@@ -700,23 +525,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) acc4[c] = mfma4(f4c(a, c), y[c][r], acc4[c]);
                 }
-            } else if constexpr (RING) {
-                // the SH head's share comes as one more period of the stream: stage r, piece ot = W2[16 ot + n][KT (4q + r) + 4 oh ..]
-                issue_after(oh * gper + L1T::HV);
-                float4 a[2][4];
-                ring_read(0, a[0]);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (r < 3) ring_read(r + 1, a[(r + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-#pragma unroll
-                        for (int ot = 0; ot < 3; ot++) osh[ot] = mm16(f4c(a[r & 1][ot], c), y[c][r], osh[ot]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ring_commit(cur ^ 1);
-                ring_barrier();
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -732,7 +540,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
             D1_TICK(4);
         }
         const int nxt = nxt_r;
-        if (!RING && nxt < FDGS_NUM_HEADS) { L1.setup_packed(packed_w1 + (size_t)nxt * W * W, lane_); L1.preload(); }
+        if (nxt < FDGS_NUM_HEADS) { L1.setup_packed(packed_w1 + (size_t)nxt * W * W, lane_); L1.preload(); }
         if (k <= 4) {
             const f32x4 sum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             f32x4 o;
@@ -743,7 +551,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
                 o[i] = tot + __shfl(bias2, i, 4);      // bias of row i sits in the lanes with (lane & 3) == i
             }
             D1_TICK(5);
-            if (!FDGS_D16_EAGER) request_inputs(hd);
             epilogue_small(hd, o);
         } else {
             // lane (n, q) holds rows 16 ot + 4q + r of the SH delta: their biases
@@ -752,7 +559,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const int m = 16 * ot + 4 * q + r; osh[ot][r] += p.b2[hd][m < k ? m : k - 1]; }
             D1_TICK(5);
-            if (!FDGS_D16_EAGER) request_inputs(hd);
             epilogue_sh(osh);
         }
         D1_TICK(6);
@@ -768,7 +574,6 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     if (d.prof && lane == 0) {
         for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], pacc[i]);
         atomicAdd(&d.prof[8], 1ull);
-        atomicAdd(&d.prof[9], pw[0]); atomicAdd(&d.prof[10], pw[1]);
     }
 #endif
 }

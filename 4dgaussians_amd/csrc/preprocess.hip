@@ -488,7 +488,7 @@ extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, v
     a.recC = at<float4>(geom, gl.recC); a.cov3D = at<float>(geom, gl.cov3D); a.tiles = at<uint32_t>(geom, gl.tiles);
     a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
     a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii; a.visibility = p->visibility;
-    a.cull = tunable("FDGS_TILE_CULL", 1) != 0; a.cullmask = at<uint4>(geom, gl.cullmask);
+    a.cull = g_tune.tile_cull != 0; a.cullmask = at<uint4>(geom, gl.cullmask);
     { FDGS_TIMED("preprocess_fwd", stream); hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
     return FDGS_OK;

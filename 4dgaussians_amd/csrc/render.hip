@@ -5,8 +5,9 @@
 // Backward (round 3): ONE wave per tile, four pixels per lane as two packed-f32 pairs (render_bwd_strip_kernel): each lane recomputes
 // alpha back-to-front, forms the per-Gaussian sums of its pixels as moments over dy, the wave adds them with a DPP / permlane
 // reduce-scatter and issues ONE 64-byte atomic line-op per (tile, Gaussian) into a packed [P,16] gradient array.  The 256-thread
-// backward of rounds 1-2 (four waves meeting in LDS slots) stays selectable (FDGS_RBWD_PPL=0), as does a strip form of the forward
-// (FDGS_RFWD_PPL, measured slower).
+// backward of rounds 1-2 (four waves meeting in LDS slots) stays selectable (tuning knob rbwd_ppl = 0; 2 = two waves per tile with two
+// pixels per lane): the three forms are compared with each other in tests/test_gpu_raster.py.  (A strip form of the FORWARD measured
+// slower and was dropped in round 3.)
 // Tile rows are dealt to the XCDs in groups (unit_of_block: workgroup b runs on XCD b % 8), so that neighbouring tiles -- which list
 // the same Gaussians -- share an XCD's 4 MiB L2 and every XCD owns rows from the whole height of the image.
 // Replaces renderCUDA forward/backward of the un-vendored rasterizer (Appendix B.3/B.4).
@@ -488,111 +489,10 @@ __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
     }
 }
 
-// ---- K6, strip form (round 3): the forward counterpart of render_bwd_strip_kernel -- one wave per 16 x (8*NP) pixel strip, NP float2
-// pixel pairs per lane sharing dx, branch-free blending (a pixel that skips an entry blends w = 0), no workgroup barriers; a strip stops
-// staging as soon as ITS pixels are saturated instead of waiting for the whole tile.
-template <int NP>
-__global__ void __launch_bounds__(64) render_fwd_strip_kernel(RenderArgs a) {
-    constexpr int PPL = 2 * NP;
-    constexpr int PARTS = 4 / PPL;
-    const int unit = unit_of_block(blockIdx.x, a.gx, a.gy, PARTS, a.bh);
-    if (unit < 0) return;
-    const int tile = unit / PARTS, part = unit - tile * PARTS;
-    __shared__ float4 sA[64], sB[64], sC[64];
-    const int lane = threadIdx.x;
-    const int x = (tile % a.gx) * TILE + (lane & 15);
-    const int y0 = (tile / a.gx) * TILE + part * (4 * PPL) + (lane >> 4);
-    const float pxf = (float)x;
-    const uint2 range = a.ranges[tile];
-    const int todo = (int)(range.y - range.x);
-    v2f py[NP], T[NP], C0[NP], C1[NP], C2[NP], Dp[NP];
-    bool done[PPL];
-    uint32_t last[PPL];
-#pragma unroll
-    for (int i = 0; i < PPL; i++) {
-        const int y = y0 + 4 * i;
-        py[i >> 1][i & 1] = (float)y;
-        done[i] = !(x < a.W && y < a.H);
-        last[i] = 0;
-    }
-#pragma unroll
-    for (int p = 0; p < NP; p++) { T[p] = splat2(1.0f); C0[p] = C1[p] = C2[p] = Dp[p] = splat2(0.f); }
-    const int rounds = (todo + 63) >> 6;
-    auto gid_of = [&](int r) -> uint32_t {
-        const int e = r * 64 + lane;
-        return a.pair_gid[range.x + (e < todo ? e : (todo > 0 ? todo - 1 : 0))];
-    };
-    uint32_t g_cur = 0, g_nxt = 0;
-    float4 rA = make_float4(0.f, 0.f, 0.f, 0.f), rB = rA, rC = rA;
-    if (rounds > 0) { g_cur = gid_of(0); rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
-    if (rounds > 1) g_nxt = gid_of(1);
-    for (int r = 0; r < rounds; r++) {
-        bool all_done = true;
-#pragma unroll
-        for (int i = 0; i < PPL; i++) all_done = all_done && done[i];
-        if (__all(all_done)) break;
-        __syncthreads();
-        sA[lane] = rA; sB[lane] = rB; sC[lane] = rC;
-        __syncthreads();
-        if (r + 1 < rounds) { g_cur = g_nxt; rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
-        if (r + 2 < rounds) g_nxt = gid_of(r + 2);
-        const int rem = todo - r * 64;
-        const int lim = rem < 64 ? rem : 64;
-        for (int j = 0; j < lim; j++) {
-            const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
-            const float4 A = sA[j];
-            const float4 B = sB[j];
-            const float4 Cc = sC[j];
-            const float dx = A.x - pxf;
-            const float u1 = blend_power_xx(A.z, dx);
-            const float cx = blend_power_xy(A.w, dx);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const v2f dy = splat2(A.y) - py[p];
-                const v2f power = blend_power2(u1, cx, B.x, dy);
-                v2f alpha;
-                alpha[0] = fminf(FDGS_ALPHA_MAX, B.y * __expf(fminf(power[0], 0.0f)));
-                alpha[1] = fminf(FDGS_ALPHA_MAX, B.y * __expf(fminf(power[1], 0.0f)));
-                const v2f test_T = T[p] * (splat2(1.0f) - alpha);
-                v2f w;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const int i = 2 * p + c;
-                    const bool cand = !done[i] && !(power[c] > 0.0f) && !(alpha[c] < FDGS_ALPHA_MIN);
-                    const bool stop = cand && (test_T[c] < FDGS_T_STOP);
-                    const bool blend = cand && !stop;
-                    done[i] = done[i] || stop;
-                    w[c] = blend ? alpha[c] * T[p][c] : 0.f;
-                    T[p][c] = blend ? test_T[c] : T[p][c];
-                    last[i] = blend ? contributor : last[i];
-                }
-                C0[p] = fma2(splat2(Cc.x), w, C0[p]); C1[p] = fma2(splat2(Cc.y), w, C1[p]); C2[p] = fma2(splat2(Cc.z), w, C2[p]);
-                Dp[p] = fma2(splat2(B.z), w, Dp[p]);
-            }
-        }
-    }
-    const size_t hw = (size_t)a.H * a.W;
-#pragma unroll
-    for (int i = 0; i < PPL; i++) {
-        const int y = y0 + 4 * i, p = i >> 1, c = i & 1;
-        if (x < a.W && y < a.H) {
-            const size_t pix = (size_t)y * a.W + x;
-            a.final_T[pix] = T[p][c]; a.n_contrib[pix] = last[i];
-            a.out_color[pix] = C0[p][c] + T[p][c] * a.bg[0];
-            a.out_color[hw + pix] = C1[p][c] + T[p][c] * a.bg[1];
-            a.out_color[2 * hw + pix] = C2[p][c] + T[p][c] * a.bg[2];
-            a.out_depth[pix] = Dp[p][c];
-        }
-    }
-}
-
 int validate_raster_params(const fdgs_raster_params* p);
 
-// tile rows per XCD group (unit_of_block): FDGS_XCD_ROWS, default 2; 0 = one contiguous band per XCD (the round-1/2 mapping)
-static int tile_rows_per_xcd_group(int gy) {
-    const int bh = tunable("FDGS_XCD_ROWS", 2);
-    return bh > 0 ? bh : (gy + 7) / 8;
-}
+// tile rows per XCD group (unit_of_block): 2 (sweep 0 / 1 / 2 / 4 in profiles/r03f_bench_cfg4_xcd*.json; 0 was one contiguous band per XCD)
+static int tile_rows_per_xcd_group(int) { return 2; }
 
 }  // namespace fdgs
 
@@ -617,14 +517,7 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     a.out_color = out_color; a.out_depth = out_depth;
     {
         FDGS_TIMED("render_fwd", stream);
-        const int ppl = tunable("FDGS_RFWD_PPL", 0);      // pixels per lane of the strip form; 0 = the 256-thread form
-        if (ppl == 2 || ppl == 4) {
-            const dim3 sgrid(unit_grid(a.gx, a.gy, 4 / ppl, a.bh));
-            if (ppl == 2) hipLaunchKernelGGL(render_fwd_strip_kernel<1>, sgrid, dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL(render_fwd_strip_kernel<2>, sgrid, dim3(64), 0, stream, a);
-        } else {
-            hipLaunchKernelGGL(render_fwd_kernel, dim3(unit_grid(a.gx, a.gy, 1, a.bh)), dim3(256), 0, stream, a);
-        }
+        hipLaunchKernelGGL(render_fwd_kernel, dim3(unit_grid(a.gx, a.gy, 1, a.bh)), dim3(256), 0, stream, a);
     }
     FDGS_LAUNCH_CHECK("render_fwd", p->debug, stream);
     return FDGS_OK;
@@ -665,11 +558,10 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         a.gacc = g->scratch_acc;
         {
             FDGS_TIMED("render_bwd", stream);
-            // entries staged per round: 128 keeps six workgroups per CU (25 KB of LDS each), 256 halves the barriers at three per CU
-            const int round = tunable("FDGS_RBWD_ROUND", 128);
+            // (256-thread form: 128 entries staged per round keeps six workgroups per CU at 25 KB of LDS each)
             const dim3 grid(unit_grid(a.gx, a.gy, 1, a.bh));
             // pixels per lane of the strip form (1 wave per workgroup); 0 = the 256-thread form
-            const int ppl = tunable("FDGS_RBWD_PPL", 4);
+            const int ppl = g_tune.rbwd_ppl;
             if (ppl == 2 || ppl == 4) {
                 const dim3 sgrid(unit_grid(a.gx, a.gy, 4 / ppl, a.bh));
 #define FDGS_STRIP(D_, P_) hipLaunchKernelGGL((render_bwd_strip_kernel<D_, P_>), sgrid, dim3(64), 0, stream, a)
@@ -678,11 +570,9 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
                 else FDGS_STRIP(false, 2);
 #undef FDGS_STRIP
             } else if (g->dL_ddepth) {
-                if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<true, 256>), grid, dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL((render_bwd_kernel<true, 128>), grid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((render_bwd_kernel<true, 128>), grid, dim3(256), 0, stream, a);
             } else {
-                if (round == 256) hipLaunchKernelGGL((render_bwd_kernel<false, 256>), grid, dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL((render_bwd_kernel<false, 128>), grid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((render_bwd_kernel<false, 128>), grid, dim3(256), 0, stream, a);
             }
         }
         FDGS_LAUNCH_CHECK("render_bwd", p->debug, stream);

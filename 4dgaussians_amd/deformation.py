@@ -376,11 +376,11 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
         saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     out.saved = ptr(saved)
     st.saved_act = saved
-    # scratch for the operand-stream copy of W0 / W1 that the 16-Gaussians-per-wave form of the forward kernel reads (the default form,
-    # FDGS_D1_FORM=16 / 17; the library re-packs the weights into it in front of every forward; without it the library runs the
-    # 32-Gaussian form).  Only handed over when that form is asked for; one persistent buffer
-    # per (device, stream, size): forwards on one stream are ordered, forwards on different streams must not share it.
-    if os.environ.get("FDGS_D1_FORM", "16") in ("16", "17", "33"):
+    # scratch for the operand-stream copy of W0 / W1 that the 16-Gaussians-per-wave form of the forward kernel reads (the default form; the
+    # library re-packs the weights into it in front of every forward; without it -- or with the tuning knob d1_form = 32 -- the library runs
+    # the 32-Gaussian form).  One persistent buffer per (device, stream, size): forwards on one stream are ordered, forwards on
+    # different streams must not share it.
+    if True:
         nbytes = _lib.c_size_t()
         check(L.fdgs_deform_pack_bytes(p, nbytes))
         key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, nbytes.value)

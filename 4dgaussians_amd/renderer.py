@@ -20,10 +20,10 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 # Fused fine stage: deformation and rasterizer behind ONE autograd node, so that the rasterizer backward's per-Gaussian chain rule
 # writes straight into the deformation backward's buffers (fdgs_raster_deform_epilogue) instead of handing five gradient tensors
 # through autograd to a separate packing kernel.  FDGS_FUSED_BACKWARD=0 keeps the two-node form (A/B, and what the tests compare with).
-FUSED_BACKWARD = __import__("os").environ.get("FDGS_FUSED_BACKWARD", "1") != "0"
+FUSED_BACKWARD = os.environ.get("FDGS_FUSED_BACKWARD", "1") != "0"
 EPILOGUE_ASSIGN = True     # False: the epilogue accumulates (+=) into a zero-filled arena (the C-ABI's other mode; tests compare both)
-# fdgs_raster_deform_epilogue::tile_flags of the fused backward.  None = 2 (dead tiles' rows unwritten, always skipped) unless the A/B knob
-# FDGS_SKIP_DEAD=0 asks for every tile to be walked (then 1: flags written, every row written).  0 / 1 / 2 force a mode (tests).
+# fdgs_raster_deform_epilogue::tile_flags of the fused backward.  None = 2 (dead tiles' rows unwritten, always skipped) unless the library's
+# tuning knob skip_dead = 0 asks for every tile to be walked (then 1: flags written, every row written).  0 / 1 / 2 force a mode (tests).
 # The deformation backward is told which mode produced its rows (packed_rows_ready = tile_flags + 1), never the environment alone.
 EPILOGUE_TILE_FLAGS = None
 
@@ -31,7 +31,7 @@ EPILOGUE_TILE_FLAGS = None
 def _tile_flags():
     if EPILOGUE_TILE_FLAGS is not None:
         return int(EPILOGUE_TILE_FLAGS)
-    return 2 if os.environ.get("FDGS_SKIP_DEAD", "1") != "0" else 1
+    return 2 if _lib.tuning_get("skip_dead") != 0 else 1
 
 
 class _FusedRenderFunction(torch.autograd.Function):

@@ -333,7 +333,7 @@ def run(args, make_step=None):
         if dom == "deform_bwd_data":
             roof["note"] = "saved activations: backward products only, live tiles only" if saved_on else "live tiles only"
         if dom == "deform_fwd":
-            form = os.environ.get("FDGS_D1_FORM", "16")
+            form = fdgs._lib.tuning_get("d1_form")
             roof["note"] = (f"forward kernel form {form} (16 = 16 Gaussians per wave, two waves per SIMD; DESIGN 3.1), timed alone; its operand-stream copy "
                             f"pack_weights ({kern.get('pack_weights', {}).get('avg_ms', 0.0):.4f} ms per launch) is a separate kernel in kernels_ms_per_step")
         roof.update(pmc_traffic(dom, args.workload, lib_sha16(fdgs)))
@@ -355,15 +355,14 @@ def run(args, make_step=None):
                               "what": "torch.no_grad() render() loop (the render.py:57-70 measurement): deformation without saved activations + rasterizer forward",
                               "kernels_ms_per_frame": {k: round(v["ms_per_step"], 4) for k, v in sorted(kf.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}}
         # ---- the same step with every tile processed by the backward (FDGS_SKIP_DEAD=0): what the live-tile lists buy on this scene
-        os.environ["FDGS_SKIP_DEAD"] = "0"
-        for i in range(3):
-            step(i)
-        rg, _ = timed_regions(step, 3, args.steps, 3, par, dev)
-        ka = kernel_times(step, max(args.steps // 2, 2))
-        os.environ.pop("FDGS_SKIP_DEAD")
+        with fdgs._lib.tuning(skip_dead=0):
+            for i in range(3):
+                step(i)
+            rg, _ = timed_regions(step, 3, args.steps, 3, par, dev)
+            ka = kernel_times(step, max(args.steps // 2, 2))
         dta = sorted(rg)[1]
         extras["all_tiles_backward"] = {"frames_per_s": world * args.steps / dta, "ms_per_step": dta / args.steps * 1e3,
-                                        "what": "FDGS_SKIP_DEAD=0: the deformation backward also walks the tiles whose gradient rows are all zero",
+                                        "what": "tuning knob skip_dead = 0: the deformation backward also walks the tiles whose gradient rows are all zero",
                                         "kernels_ms_per_step": {k: round(ka[k]["ms_per_step"], 4) for k in ("deform_bwd_data", "deform_wgrad", "deform_plane_grad") if k in ka}}
         # ---- the OTHER scene statistic: a surface-like translucent scene in which nearly every visible Gaussian receives a gradient (no dead
         # tiles to skip; long per-pixel walks) -- where a trained model without mass occlusion would land

@@ -43,6 +43,15 @@ int fdgs_abi_version(void);
  * roofline measurement).  fdgs_timing_report synchronises the device and writes "kernel_name count total_ms" lines. */
 int fdgs_timing_enable(int on);
 int fdgs_timing_report(char* buf, size_t buflen, int reset);
+/* Development / test knobs (ABI 4).  The library holds ONE table of eight integer knobs; it is filled from the environment variables
+ * FDGS_<NAME> once, when the library is loaded, and afterwards changes only through fdgs_tuning_set -- no entry point reads the
+ * environment.  Knobs select between equivalent kernel forms or launch shapes (same results up to summation order), never semantics:
+ *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (4 | 2 | 0).
+ * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
+ * set knobs between frames.  fdgs_tuning_reset restores the load-time values.  See INTEGRATION.md ("Knobs"). */
+int fdgs_tuning_set(const char* name, int value);
+int fdgs_tuning_get(const char* name, int* value);
+int fdgs_tuning_reset(void);
 /* Name (gcnArchName) of device `dev` into buf; FDGS_E_NOGPU if none. */
 int fdgs_device_arch(int dev, char* buf, size_t buflen);
 
@@ -221,8 +230,8 @@ typedef struct fdgs_deform_out {
                          heads' W1 into it as the operand streams of its matrix-core loops (contiguous 1-KB loads instead of 64 cache lines
                          per request) and runs its 16-Gaussians-per-wave form, two waves per SIMD -- the faster form inside a frame
                           and what the Python host hands over by default; NULL: the 32-Gaussian form on the row-major
-                         weights.  Same results up to summation order, same `saved` format.  (Environment FDGS_D1_FORM=32 / 17 selects the
-                         32-Gaussian form / the LDS-ring variant of the 16-form for A/B runs.) */
+                         weights.  Same results up to summation order, same `saved` format.  (Tuning knob d1_form = 32 forces the
+                         32-Gaussian form for A/B runs.) */
 } fdgs_deform_out;
 
 int fdgs_deform_saved_bytes(const fdgs_deform_params* p, size_t* bytes);
@@ -250,7 +259,7 @@ typedef struct fdgs_deform_grads {
      *    tile_flags = 0); the g_* / out_* / rot_norm pointers above are then ignored.  No flags: every tile is walked.
      * 2: as 1, and the rows are followed by the per-tile non-zero flags (epilogue tile_flags = 1): all-zero tiles are skipped.
      * 3: as 2, and the rows of tiles flagged 0 were NOT written (epilogue tile_flags = 2): all-zero tiles are ALWAYS skipped.
-     * (The development knob FDGS_SKIP_DEAD=0 makes modes 0 and 2 walk every tile for A/B runs; it cannot affect modes 1 and 3.) */
+     * (The tuning knob skip_dead = 0 makes modes 0 and 2 walk every tile for A/B runs; it cannot affect modes 1 and 3.) */
     int packed_rows_ready;
     /* hint, never needed for correctness: 1 = consecutive Gaussians are spatial neighbours (the set is kept along a space-filling
      * curve, fdgs.densify.spatial_reorder): with one frame time for all Gaussians the plane gradient then runs as the windowed

@@ -21,3 +21,18 @@ def fdgs():
 
 def have_reference():
     return os.path.isdir("/root/reference/scene")
+
+
+def set_knob(name, value):
+    """Set one of libfdgs's development knobs (fdgs_tuning_set; replaces the FDGS_* environment variables the library used to read per call).
+    The autouse fixture below restores the load-time values after every test."""
+    importlib.import_module("4dgaussians_amd._lib").tuning_set(name, int(value))
+
+
+@pytest.fixture(autouse=True)
+def _reset_knobs_after_test(request):
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        L = importlib.import_module("4dgaussians_amd._lib")
+        if L._lib is not None:
+            L._lib.fdgs_tuning_reset()

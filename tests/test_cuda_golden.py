@@ -9,6 +9,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import set_knob
 import torch
 
 from scenes import rel_l2
@@ -108,7 +110,7 @@ def test_hip_stage_tensors_match_reference_cuda(path, monkeypatch):
     z = np.load(path)
     if "stage.depths" not in z.files:
         pytest.skip("golden file written by an older dump script (no stage tensors)")
-    monkeypatch.setenv("FDGS_TILE_CULL", "0")
+    set_knob("tile_cull", "0")
     dev = torch.device("cuda:0")
     sc = _scene(z)
     H, W, P = sc["image_height"], sc["image_width"], sc["means3D"].shape[0]

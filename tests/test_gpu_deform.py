@@ -5,6 +5,8 @@ import math
 
 import numpy as np
 import pytest
+
+from conftest import set_knob
 import torch
 
 from oracle import deform_oracle as DO
@@ -61,26 +63,25 @@ def test_deform_forward_backward_parity(cfg, n, activate):
 
 @pytest.mark.parametrize("cfg,n,t", [("dnerf_bouncingballs", 1000, None), ("hypernerf_default", 257, None), ("dynerf_default", 1531, None),
                                      ("dynerf_default", 31, None), ("dynerf_default", 40100, 0.37), ("hypernerf_default", 5000, 1.0)])
-@pytest.mark.parametrize("form", ["32", "17", "33"])
-def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form, monkeypatch):
-    """The forms of the forward kernel that are NOT the default.  (Default, exercised by every other test here: FDGS_D1_FORM=16, the
+@pytest.mark.parametrize("form", ["32"])
+def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form):
+    """The form of the forward kernel that is NOT the default.  (Default, exercised by every other test here: tuning knob d1_form = 16, the
     16-Gaussians-per-wave form of csrc/deform_fwd16.h: v_mfma_f32_16x16x4_f32, two waves per SIMD, W0 / W1 read as packed operand streams.)
-    FDGS_D1_FORM=32: one wave = 32 Gaussians on v_mfma_f32_32x32x2_f32, one wave per SIMD (the default until round 4, and what the library
-    runs when the caller hands over no pack scratch) -- same oracle, same tolerances, forward AND the backward that consumes its saved
-    activations and ReLU bit masks; sizes with a partial last tile, a single tile, and the leftover-tile split of the persistent loop.
-    FDGS_D1_FORM=17: the same form with the operand streams handed through a per-workgroup LDS ring (one quarter of the vector-memory
-    requests per wave, one s_barrier per 16-KB period, the SH head's second layer in the stream)."""
-    monkeypatch.setenv("FDGS_D1_FORM", form)
+    d1_form = 32: one wave = 32 Gaussians on v_mfma_f32_32x32x2_f32, one wave per SIMD (the default until round 4, and what the library
+    runs when the caller hands over no pack scratch or C*L is not a multiple of 16) -- same oracle, same tolerances, forward AND the backward
+    that consumes its saved activations and ReLU bit masks; sizes with a partial last tile, a single tile, and the leftover-tile split of the
+    persistent loop."""
+    set_knob("d1_form", form)
     _parity(cfg, n, True, scalar_time=t)
 
 
-@pytest.mark.parametrize("form", ["16", "17", "32", "33"])
-def test_deform_parity_leftover_tiles_split_by_head(form, monkeypatch):
-    """The persistent loop of the forward kernel deals the tiles left over after its last full round out BY HEAD (waves in forms 16 / 32 / 33,
-    whole workgroups in the ring form 17).  At test sizes that branch is only taken with a small grid: 5 000 Gaussians on 13 workgroups leave
-    8 of 320 tiles (form 16), 2 of 80 tile quads (form 17), 4 of 160 tiles (forms 32 / 33) for the split round."""
-    monkeypatch.setenv("FDGS_D1_FORM", form)
-    monkeypatch.setenv("FDGS_D1_WGS", "13")
+@pytest.mark.parametrize("form", ["16", "32"])
+def test_deform_parity_leftover_tiles_split_by_head(form):
+    """The persistent loop of the forward kernel deals the tiles left over after its last full round out BY HEAD over the waves.  At test
+    sizes that branch is only taken with a small grid: 5 000 Gaussians on 13 workgroups leave 8 of 320 tiles (form 16) / 4 of 160 tiles
+    (form 32) for the split round."""
+    set_knob("d1_form", form)
+    set_knob("d1_wgs", "13")
     _parity("dynerf_default", 5000, True, scalar_time=0.61)
 
 
@@ -397,7 +398,7 @@ def _plane_grads(cfg, n, order, t, mfma, monkeypatch, seed=13, spread=1.0):
     """d(planes), d(xyz) of sum(out * w) through the HIP backward with one frame time; inputs optionally Hilbert-ordered."""
     dev = torch.device("cuda:0")
     fd = _fdgs()
-    monkeypatch.setenv("FDGS_D4_MFMA", "1" if mfma else "0")
+    set_knob("d4_mfma", "1" if mfma else "0")
     args, net, ins = _net_and_inputs(cfg, n, seed, dev, safe=False, fixed_time=t)
     ins[0] = ins[0] * spread
     if order != "random":
@@ -457,9 +458,9 @@ def test_plane_grad_mfma_splat_vs_oracle_on_ordered_input(cfg, n, t, monkeypatch
 def test_plane_grad_mfma_time_rows_that_do_not_fit_lds(rows_kb, monkeypatch):
     """When the private time rows of a level do not fit the workgroup's LDS (large planes, many levels) that level's time planes take
     global atomics in the miss pass: forced here by capping the budget (0 KB: no level fits; 20 KB: level 0 fits, level 1 does not)."""
-    monkeypatch.setenv("FDGS_D4_ROWS_KB", str(rows_kb))
+    set_knob("d4_rows_kb", str(rows_kb))
     a, _ = _plane_grads("dynerf_default", 6000, "hilbert", 0.61, True, monkeypatch)
-    monkeypatch.delenv("FDGS_D4_ROWS_KB")
+    set_knob("d4_rows_kb", -1)
     b, _ = _plane_grads("dynerf_default", 6000, "hilbert", 0.61, False, monkeypatch)
     errs = [rel_l2(x.numpy(), y.numpy()) for x, y in zip(a, b)]
     assert errs[0] < 1e-5 and max(errs[1:]) < 2e-5
@@ -498,7 +499,7 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     monkeypatch.setattr(fd.deformation, "COUNT_LIVE_TILES", True)
     res = {}
     for skip in ("1", "0"):
-        monkeypatch.setenv("FDGS_SKIP_DEAD", skip)
+        set_knob("skip_dead", skip)
         gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
         out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.43, activate=True, ordered=ordered)
         params = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
@@ -543,7 +544,7 @@ def test_leftover_tiles_split_by_head_changes_nothing(cfg, n, monkeypatch):
     ws = [torch.randn(s, generator=torch.Generator().manual_seed(4)).to(dev) for s in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 16, 3))]
     res = {}
     for split in ("1", "0"):
-        monkeypatch.setenv("FDGS_D1_SPLIT", split)
+        set_knob("d1_split", split)
         gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
         out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.61, activate=True)
         params = [p for _, p in net.named_parameters() if p.requires_grad]

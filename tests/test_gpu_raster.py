@@ -4,6 +4,8 @@ import math
 
 import numpy as np
 import pytest
+
+from conftest import set_knob
 import torch
 
 from oracle.raster_oracle import RasterOracle
@@ -119,7 +121,7 @@ def _culled_pairs_contribute_nothing(o, listed_gid, listed_tile, ok, W, H):
 @pytest.mark.parametrize("cull", [False, True])
 @pytest.mark.parametrize("case", CASES)
 def test_stagewise_forward_parity(case, cull, monkeypatch):
-    monkeypatch.setenv("FDGS_TILE_CULL", "1" if cull else "0")
+    set_knob("tile_cull", "1" if cull else "0")
     dev = torch.device("cuda:0")
     sc = raster_scene(**case)
     o = RasterOracle(**sc)
@@ -307,7 +309,7 @@ def test_tile_culling_is_exact(case, monkeypatch):
     R = _mod().rasterizer
     outs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("FDGS_TILE_CULL", flag)
+        set_knob("tile_cull", flag)
         t = {k: torch.tensor(sc[k], device=dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
         m2d = torch.zeros(t["means3D"].shape[0], 3, device=dev, requires_grad=True)
         color, radii, depth = R.GaussianRasterizer(_settings(sc, dev))(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
@@ -329,9 +331,8 @@ def test_tile_culling_is_exact(case, monkeypatch):
 @pytest.mark.parametrize("with_depth", [False, True])
 def test_blending_kernel_forms_agree(with_depth, monkeypatch):
     """The blending kernels exist in several shapes selected by development knobs -- backward: one wave per tile with four pixels per
-    lane (default), two waves with two pixels per lane (FDGS_RBWD_PPL=2), the 256-thread form of rounds 1-2 (FDGS_RBWD_PPL=0);
-    forward: the 256-thread form (default) and the strip forms (FDGS_RFWD_PPL=2/4).  All of them must produce the same image,
-    the same per-pixel bookkeeping and the same gradients up to the association of the sums."""
+    lane (default), two waves with two pixels per lane (rbwd_ppl = 2), the 256-thread form of rounds 1-2 (rbwd_ppl = 0).  All of them
+    must produce the same gradients up to the association of the sums (and the forward, which has one form, the same image every time)."""
     dev = torch.device("cuda:0")
     sc = raster_scene(6000, 232, 152, seed=11, scale_boost=2.0)
     R = _mod().rasterizer
@@ -339,12 +340,8 @@ def test_blending_kernel_forms_agree(with_depth, monkeypatch):
     wc = torch.tensor(rng.standard_normal((3, 152, 232)).astype(np.float32), device=dev)
     wd = torch.tensor(rng.standard_normal((1, 152, 232)).astype(np.float32), device=dev)
     outs = {}
-    for name, env in (("default", {}), ("bwd2", {"FDGS_RBWD_PPL": "2"}), ("bwd0", {"FDGS_RBWD_PPL": "0"}), ("fwd2", {"FDGS_RFWD_PPL": "2"}),
-                      ("fwd4", {"FDGS_RFWD_PPL": "4"}), ("bands", {"FDGS_XCD_ROWS": "0"})):
-        for k in ("FDGS_RBWD_PPL", "FDGS_RFWD_PPL", "FDGS_XCD_ROWS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for name, ppl in (("default", 4), ("bwd2", 2), ("bwd0", 0)):
+        set_knob("rbwd_ppl", ppl)
         t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
         means2D = torch.zeros_like(t["means3D"], requires_grad=True)
         rast = R.GaussianRasterizer(_settings(sc, dev))

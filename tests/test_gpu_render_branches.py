@@ -13,6 +13,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import set_knob
 import torch
 
 from scenes import rel_l2
@@ -295,7 +297,7 @@ def test_backward_skips_tiles_the_rasterizer_gave_no_gradient(monkeypatch):
     monkeypatch.setattr(fd.deformation, "COUNT_LIVE_TILES", True)
     runs = {}
     for skip in ("1", "0"):
-        monkeypatch.setenv("FDGS_SKIP_DEAD", skip)
+        set_knob("skip_dead", skip)
         res, g, v = _render_and_grads(pc, cam, _Pipe(), "fine", w)
         runs[skip] = (res, g, v, fd.deformation.last_live_tiles)
     vis = float((runs["1"][0]["radii"] > 0).float().mean())
@@ -310,7 +312,7 @@ def test_backward_skips_tiles_the_rasterizer_gave_no_gradient(monkeypatch):
     # packed_rows_ready = 1 (epilogue tile_flags = 0: rows without flags) and 2 (flags, every row written): the C-ABI's other two modes.
     # Mode 1 once read per-tile flags nothing had written: the scratch block is recycled by the caching allocator, so a
     # backward of ANOTHER camera in skip mode first leaves that camera's 0 / 1 flags where mode 1 would have looked
-    monkeypatch.setenv("FDGS_SKIP_DEAD", "1")
+    set_knob("skip_dead", "1")
     other = synthetic.make_camera(320, 240, theta_deg=200.0, time=0.6, radius=1.2).to(dev)
     for mode in (0, 1):
         _render_and_grads(pc, other, _Pipe(), "fine", w)

@@ -46,10 +46,3 @@ def test_mfma16_model_matches_definition():
     for (n, q, r) in ((0, 0, 0), (5, 2, 3), (15, 3, 1)):
         row = 4 * q + r
         assert np.isclose(d[n + 16 * q, r], sum(a[row + 16 * kk] * b[n + 16 * kk] for kk in range(4)))
-
-
-@pytest.mark.parametrize("WT,k", [(4, 3), (4, 48), (4, 1), (2, 4), (2, 48)])
-def test_group_wise_32_gaussian_form_consistent(WT, k):
-    """csrc/deform_fwd32g.h (FDGS_D1_FORM=33): packed first-layer stream, standard-order output tiles, parked tiles in feature order,
-    the tile-wise share of both second-layer forms, the block-wise parking of the interleaved trunk output."""
-    assert model.check32g(WT, k, np.random.default_rng(10 * WT + k))

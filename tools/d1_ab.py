@@ -35,5 +35,5 @@ def run(grad, n=20):
             return float(tot) / int(cnt)
 
 
-tag = f"skew={os.environ.get('FDGS_D16_SKEW', '-')} lib={os.path.basename(os.environ.get('FDGS_LIB', 'libfdgs.so'))} form={os.environ.get('FDGS_D1_FORM', '16')} wgs={os.environ.get('FDGS_D1_WGS', '-')}"
+tag = f"lib={os.path.basename(os.environ.get('FDGS_LIB', 'libfdgs.so'))} form={os.environ.get('FDGS_D1_FORM', '16')} wgs={os.environ.get('FDGS_D1_WGS', '-')}"
 print(f"[d1_ab] {tag}: deform_fwd saving {run(True):.4f} ms, forward-only {run(False):.4f} ms", flush=True)

@@ -343,77 +343,3 @@ if __name__ == "__main__":
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
-# The group-wise 32-Gaussian form of the forward kernel (csrc/deform_fwd32g.h, FDGS_D1_FORM=33): trunk output interleaved, a head's hidden layer
-# one STANDARD 32-row output tile at a time, the tile's share of the second layer behind its ReLU, parked [32][32] tiles in feature order.
-def pack32g(W1, WT):
-    """pack_weights32g_kernel: stream[idx][lane] = W1[32 ot + g][WT (4h + rho(s, 0)) .. + WT - 1], idx = 16 ot + s."""
-    out = np.zeros((16 * WT, 64, WT))
-    for idx in range(16 * WT):
-        ot, s = idx >> 4, idx & 15
-        for t in range(WT):
-            out[idx, :, t] = W1[32 * ot + G, WT * (4 * H + rho(s, 0)) + t]
-    return out
-
-
-def check32g(WT, k, rng):
-    W = 32 * WT
-    hid_m = np.maximum(rng.standard_normal((32, W)), 0.0)
-    W1, b1 = rng.standard_normal((W, W)), rng.standard_normal(W)
-    W2, b2 = rng.standard_normal((k, W)), rng.standard_normal(k)
-    hid = matrix_to_il(hid_m, WT)
-    stream = pack32g(W1, WT)
-    h1_ref = np.maximum(hid_m @ W1.T + b1, 0.0)
-    out_ref = h1_ref @ W2.T + b2
-    ok = True
-    # saved relu(hidden): park_rh(jb) writes the 32-feature block jb of every Gaussian's row in feature order
-    RPP = 16 // WT
-    for jb in range(WT):
-        tile = np.full((32, 32), np.nan)
-        for x in range(RPP):
-            r = RPP * jb + x
-            off = WT * ((x & 3) + 8 * (x >> 2) + 4 * H)
-            for t in range(WT):
-                tile[G, off + t] = hid[t][:, r]
-        ok &= np.allclose(tile, hid_m[:, 32 * jb:32 * jb + 32])
-    saved_h1 = np.zeros((32, W))
-    acc4 = [np.zeros((64, 4)) for _ in range(4)]
-    row2 = np.minimum(LANES & 3, k - 1)
-    r0, r1 = np.minimum(G, k - 1), np.minimum(32 + G, k - 1)
-    o0 = mfma32(np.where(H == 0, b2[r0], 0.0), np.ones(64), np.zeros((64, 16)))
-    o1 = mfma32(np.where(H == 0, b2[r1], 0.0), np.ones(64), np.zeros((64, 16)))
-    for ot in range(WT):
-        Y = mfma32(np.where(H == 0, b1[32 * ot + G], 0.0), np.ones(64), np.zeros((64, 16)))
-        for s in range(16):
-            cur = stream[16 * ot + s]
-            for t in range(WT):
-                Y = mfma32(cur[:, t], hid[t][:, s], Y)
-        Y = np.maximum(Y, 0.0)
-        # park_tile: register r = feature rho(r, h) of the tile; drain: piece jp = rows 8 jp .. + 7, 128 contiguous bytes per row
-        tile = np.full((32, 32), np.nan)
-        for j in range(4):
-            for c in range(4):
-                tile[G, 8 * j + 4 * H + c] = Y[:, 4 * j + c]
-        for jp in range(4):
-            e4 = jp * 64 + LANES
-            row, c4 = e4 >> 3, e4 & 7
-            for c in range(4):
-                saved_h1[row, 32 * ot + 4 * c4 + c] = tile[row, 4 * c4 + c]
-        # the tile's share of the second layer
-        for j in range(4):
-            if k <= 4:
-                for c in range(4):
-                    acc4[c] = mfma4(W2[row2, 32 * ot + 8 * j + 4 * H + c], Y[:, 4 * j + c], acc4[c])
-            else:
-                for c in range(4):
-                    o0 = mfma32(W2[r0, 32 * ot + 8 * j + 4 * H + c], Y[:, 4 * j + c], o0)
-                    o1 = mfma32(W2[r1, 32 * ot + 8 * j + 4 * H + c], Y[:, 4 * j + c], o1)
-    ok &= np.allclose(saved_h1, h1_ref)
-    if k <= 4:
-        s = acc4[0] + acc4[1] + acc4[2] + acc4[3]
-        tot = s + s[LANES ^ 32]
-        out = tot + b2[np.minimum(np.arange(4), k - 1)][None, :]
-        ok &= np.allclose(out[:32, :k], out_ref)
-    else:
-        out = np.concatenate([tile_to_matrix([o0], 1), tile_to_matrix([o1], 1)], 1)[:, :k]
-        ok &= np.allclose(out, out_ref)
-    return bool(ok)
