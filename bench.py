@@ -389,6 +389,18 @@ def run(args, make_step=None):
                                     "backward_live_tiles": {"live": lt[0], "tiles": lt[1], "frac": round(lt[0] / max(lt[1], 1), 4)},
                                     "deform_bwd_data_frac_of_f32_mfma_peak": (d2_flops / (ks["deform_bwd_data"]["avg_ms"] * 1e-3) / MFMA_F32_PEAK) if "deform_bwd_data" in ks else None,
                                     "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"])[:9]}}
+        if not args.no_cpu_baseline:
+            # the same self-check as the headline frame, on THIS scene (one oracle frame on the host, outside every timed region)
+            def other_leg():
+                cam_p = cams[args.warmup % len(cams)]
+                _, ref_s = cpu_baseline(fdgs, syn, pc_s, cam_p, target, dcfg, 1)
+                prm_s = [p_ for p_ in pc_s.parameters() if p_.requires_grad]
+                full = parity_vs_oracle(fdgs, pc_s, cam_p, pipe, bg, prm_s, ref_s)
+                keep = ("image_psnr_dB", "n_pixels_over_1e-4", "n_pixels", "radii_mismatch_frac", "grad_rel_l2_vs_float64_oracle",
+                        "grad_rel_l2_vs_float64_oracle_kink_rows_attributed", "kink_rows", "n_kink_rows", "max_kink_rows", "unexplained_rows",
+                        "n_unexplained_rows", "attribution_windows", "grad_ok", "grad_failures", "viewspace_rel_l2")
+                return {k: full[k] for k in keep}
+            extras[other + "_scene"]["parity"] = rank0_leg(par, rank, other_leg)
         del pc_s, step_s
         torch.cuda.empty_cache()
         # ---- the generator's (random) order of the same scene: no spatial locality, no contiguous dead tiles
@@ -707,7 +719,7 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
             "grad_rel_l2_vs_float64_oracle_kink_rows_attributed": att["grad_rel_l2_vs_float64_kink_rows_attributed"],
             "kink_rows": att["kink_rows"], "n_kink_rows": att["n_kink_rows"], "max_kink_rows": att["max_kink_rows"],
             "heavy_rows_within_tol_rowwise": att["heavy_rows_within_tol_rowwise"], "unexplained_rows": att["unexplained_rows"],
-            "n_unexplained_rows": att["n_unexplained_rows"], "grad_rule": att["rule"],
+            "n_unexplained_rows": att["n_unexplained_rows"], "grad_rule": att["rule"], "attribution_windows": att["windows"],
             "grad_ok": att["ok"], "grad_failures": att["failures"],
             # for information: the same HIP gradients against the oracle's own float32 autograd (which has the same kinks as any float32 evaluation)
             "grad_rel_l2_vs_float32_oracle_info": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},

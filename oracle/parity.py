@@ -9,9 +9,20 @@ module replaces that with an attribution that names the rows:
   reference  = float64 evaluation of the pinned oracle (deform_oracle.backward_float64) -- ONE reference, always.
   K          = rows whose per-Gaussian gradient differs from the reference by more than `row_tol` x the tensor's norm.
   a row of K is ATTRIBUTED only when it is a PROVEN kink row: in the float64 forward of that row some ReLU pre-activation lies within the
-               float32 forward-error bound of zero (or a plane coordinate within rounding of a texel boundary / the border), and the
-               implementation's row equals -- row-wise, to `variant_tol` -- the float64 evaluation of that SAME row with a subset of exactly
-               those decisions taken the other way (deform_oracle.KinkDecisions).  Any other row of K is left as it is (`unexplained_rows`: in a
+               float32 forward error of zero (or a plane coordinate within rounding of a texel boundary / the border), and the
+               implementation's row equals -- row-wise, to `variant_tol` = 1e-3 -- the float64 evaluation of that SAME row with a subset of
+               exactly those decisions taken the other way (deform_oracle.KinkDecisions).  Every attributed row REPORTS THE MARGIN that
+               admitted it: |pre-activation| in units of u32 * (sum |w_i x_i| + |b|) for a ReLU, the distance to the texel boundary in
+               texels and in float32 ulps of the axis extent for a cell / border decision.
+  windows    = what a float32 evaluation of the REFERENCE'S OWN arithmetic is measured to differ from its float64 evaluation by
+               (tools/parity_windows.py, profiles/r05_parity_windows_float32_vs_float64.txt; asserted by
+               tests/test_oracle_parity.py::test_windows_are_what_float32_rounding_justifies): trunk pre-activations by up to 119 .. 348
+               u32-units over 20 k .. 100 k Gaussians and three deformation configs (the inputs of the trunk are products of six bilinear
+               samples whose weights move with the coordinate's rounding, so the error is far above the dot product's own ~sqrt(K) u; it
+               is a tail, the maximum grows slowly with the sample), head pre-activations by up to 39 .. 101, coordinates by 2.2 ulp32 of
+               the axis extent = 8.3e-6 (64 texels) .. 4.1e-5 texels (256 texels).  Windows: RELU_WINDOW = 512 (trunk) / 160 (heads)
+               u32-units, CELL_EPS = 1e-4 texels -- 1.5x .. 2.5x the measured maxima.  (Round 4: 256 / 256 u32-units -- too tight for
+               the trunk by this measurement, 1.6x too wide for the heads --, 2e-3 texels -- 50x too wide --, row-wise tolerance 2e-3.)  Any other row of K is left as it is (`unexplained_rows`: in a
                rendered frame, Gaussians whose upstream gradient moved with one of the rasterizer's alpha >= 1/255 decisions), counts fully in
                the group figures, and fails on its own above `unexplained_tol` = 5e-4 of a tensor's norm.
   groups     = every parameter group is then compared with the float64 reference in which the ATTRIBUTED rows (their rows of the per-Gaussian
@@ -61,12 +72,23 @@ def _row_eval(sd64, flags, leaves, row, t_value, gouts, dec):
     return {k: (None if x is None else x.numpy()) for k, x in zip(names, grads)}
 
 
-def kink_items(sd64, flags, leaves, row, t_value, relu_factor=256.0, cell_eps=2e-3, max_items=7):
+RELU_WINDOW = {"trunk": 512.0, "head": 160.0}     # u32-units of sum |w x| + |b| (module docstring: measured up to 348 / 101 for the reference itself)
+CELL_EPS = 1e-4                                    # texels (measured 8.3e-6 .. 4.1e-5 for the reference itself on 64 .. 256-texel axes)
+
+
+def _ulp32(x):
+    x = abs(float(x))
+    return 2.0 ** (math.floor(math.log2(x)) - 23) if x > 0 else 2.0 ** -149
+
+
+def kink_items(sd64, flags, leaves, row, t_value, relu_window=None, cell_eps=None, max_items=7):
     """The decisions of row `row` a float32 evaluation may legitimately take the other way: ReLU inputs with
-    |pre-activation| <= relu_factor * u32 * (sum |w_i x_i| + |b|) (a generous multiple of the float32 dot-product forward-error bound, which
-    also covers the rounding carried in by the layer's inputs), spatial plane coordinates within `cell_eps` texels of a texel boundary
-    (float32 places p = (c+1)/2 (size-1) to ~size * 1e-7; the HexPlane kernels may also form it as one fused multiply-add).
-    Returns [(margin, kind, key, payload)], nearest first, at most `max_items`."""
+    |pre-activation| <= relu_window[layer] * u32 * (sum |w_i x_i| + |b|), spatial plane coordinates within `cell_eps` texels of a texel
+    boundary / the border (windows: module docstring).
+    Returns [(rel, kind, key, payload, margin)], nearest first (rel = margin / window), at most `max_items`; `margin` is what the report
+    prints: {"u32_units": ...} for a ReLU, {"texels": ..., "ulp32_of_extent": ...} for a cell / border decision."""
+    relu_window = RELU_WINDOW if relu_window is None else relu_window
+    cell_eps = CELL_EPS if cell_eps is None else cell_eps
     dt = torch.float64
     dec = DO.KinkDecisions(1)
     with torch.no_grad():
@@ -76,9 +98,10 @@ def kink_items(sd64, flags, leaves, row, t_value, relu_factor=256.0, cell_eps=2e
                           torch.full((1, 1), float(t_value), dtype=dt), decisions=dec)
         items = []
         for layer, (pre, absdot) in dec.captured.items():
-            rel = (pre.abs() / (absdot * U32 * relu_factor).clamp_min(1e-300))[0]
-            for j in torch.nonzero(rel <= 1.0).flatten().tolist():
-                items.append((float(rel[j]), "relu", layer, j))
+            win = relu_window["trunk" if layer == "trunk" else "head"]
+            units = (pre.abs() / (absdot * U32).clamp_min(1e-300))[0]
+            for j in torch.nonzero(units <= win).flatten().tolist():
+                items.append((float(units[j]) / win, "relu", layer, j, {"u32_units": float(f"{float(units[j]):.3g}"), "window": win}))
         aabb = sd64["deformation_net.grid.aabb"]
         pts = ((x - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0)[0]
         for lvl in range(DO.count_levels(sd64)):
@@ -87,22 +110,36 @@ def kink_items(sd64, flags, leaves, row, t_value, relu_factor=256.0, cell_eps=2e
                 size = pl.shape[3] if axis == 0 else pl.shape[2]
                 p = float((pts[axis] + 1.0) / 2.0 * (size - 1))
                 inside = 0 < p < size - 1
+                mg = lambda d: {"texels": float(f"{d:.3g}"), "ulp32_of_extent": float(f"{d / _ulp32(size - 1):.3g}"), "window_texels": cell_eps}
                 if min(abs(p), abs(p - (size - 1))) <= cell_eps:
-                    items.append((min(abs(p), abs(p - (size - 1))) / cell_eps, "gate", (lvl, axis), None))
+                    d = min(abs(p), abs(p - (size - 1)))
+                    items.append((d / cell_eps, "gate", (lvl, axis), None, mg(d)))
                 if inside:
                     fl = math.floor(p)
                     frac = p - fl
                     if frac <= cell_eps and fl - 1 >= 0:
-                        items.append((frac / cell_eps, "cell", (lvl, axis), -1))
+                        items.append((frac / cell_eps, "cell", (lvl, axis), -1, mg(frac)))
                     elif 1 - frac <= cell_eps and fl + 1 <= size - 2:
-                        items.append(((1 - frac) / cell_eps, "cell", (lvl, axis), +1))
+                        items.append(((1 - frac) / cell_eps, "cell", (lvl, axis), +1, mg(1 - frac)))
     items.sort(key=lambda it: it[0])
     return items[:max_items]
 
 
+def _widest(kink_rows):
+    """The largest margin that admitted a decision of an attributed row, per kind (None when no row was attributed)."""
+    out = {"relu_u32_units": None, "cell_texels": None}
+    for r in kink_rows:
+        for m in r.get("margins", []):
+            if "u32_units" in m:
+                out["relu_u32_units"] = max(out["relu_u32_units"] or 0.0, m["u32_units"])
+            else:
+                out["cell_texels"] = max(out["cell_texels"] or 0.0, m["texels"])
+    return out
+
+
 def _decisions_for(subset, width_of):
     dec = DO.KinkDecisions(1)
-    for (_, kind, key, payload) in subset:
+    for (_, kind, key, payload, _m) in subset:
         if kind == "relu":
             f = dec.relu_flip.setdefault(key, torch.zeros(1, width_of[key], dtype=torch.bool))
             f[0, payload] = True
@@ -113,7 +150,7 @@ def _decisions_for(subset, width_of):
     return dec
 
 
-def attribute(sd, flags, leaves, t_value, gouts, impl, ref64, row_tol=1e-4, variant_tol=2e-3, tol=1e-3, max_rows=None, unexplained_tol=5e-4):
+def attribute(sd, flags, leaves, t_value, gouts, impl, ref64, row_tol=1e-4, variant_tol=1e-3, tol=1e-3, max_rows=None, unexplained_tol=5e-4):
     """Compare an implementation's gradients `impl` ({name: numpy}) with the float64 reference `ref64` (deform_oracle.backward_float64 of the
     same `sd`, `leaves`, `gouts`) under the rule in the module docstring.  Returns a report dict; report["ok"] says whether every assertion
     holds (callers assert on it and print report["failures"]).  `sd`: state_dict tensors of the oracle chain (requires_grad marks the
@@ -166,7 +203,9 @@ def attribute(sd, flags, leaves, t_value, gouts, impl, ref64, row_tol=1e-4, vari
         e, subset, var = best
         kink_rows.append({"row": int(r), "diff_over_tensor_norm": float(f"{cand[r]:.3e}"), "near_kink_decisions": len(items),
                           "row_rel_l2_unflipped": float(f"{e0:.3e}"),
-                          "matched": [f"{kind}:{key}:{payload}" for (_, kind, key, payload) in subset], "row_rel_l2_to_matched_variant": float(f"{e:.3e}")})
+                          "matched": [f"{kind}:{key}:{payload}" for (_, kind, key, payload, _m) in subset],
+                          "margins": [m_ for (_, _k, _key, _p, m_) in subset],       # what admitted each matched decision (units: kink_items)
+                          "row_rel_l2_to_matched_variant": float(f"{e:.3e}")})
         # A row no kink variant explains differs for another reason -- in a rendered frame: the rasterizer upstream took an alpha >= 1/255 /
         # T < 1e-4 decision the other way on one of the Gaussian's pixels (the image comparison counts those pixels), which moves that
         # Gaussian's upstream gradient.  Such rows are REPORTED and count fully in the group figures below; one that carries more than
@@ -196,6 +235,9 @@ def attribute(sd, flags, leaves, t_value, gouts, impl, ref64, row_tol=1e-4, vari
             "grad_rel_l2_vs_float64_kink_rows_attributed": {g: float(f"{v:.3e}") for g, v in attributed.items()},
             "kink_rows": kink_rows, "n_kink_rows": len(kink_rows), "max_kink_rows": max_rows, "n_gaussians": n,
             "heavy_rows_within_tol_rowwise": heavy_rows[:8], "unexplained_rows": unexplained[:8], "n_unexplained_rows": len(unexplained),
+            "windows": {"relu_u32_units": dict(RELU_WINDOW), "cell_texels": CELL_EPS, "variant_tol": variant_tol,
+                        "widest_margin_admitted": _widest(kink_rows)},
             "rule": f"a row differing by > {row_tol:g} of a tensor's norm is attributed only if it equals (row-wise, <= {variant_tol:g}) the float64 evaluation of "
-                    f"the same Gaussian with near-zero ReLU / texel-boundary decisions flipped; other such rows are listed as unexplained, count in the group "
+                    f"the same Gaussian with near-zero ReLU (|pre| <= {RELU_WINDOW['trunk']:g} / {RELU_WINDOW['head']:g} u32 * sum|wx|, trunk / heads) or "
+                    f"texel-boundary (<= {CELL_EPS:g} texel) decisions flipped -- each row prints its margin; other such rows are listed as unexplained, count in the group "
                     f"figures and fail above {unexplained_tol:g} on their own; groups <= {tol:g} with the attributed rows replaced by the matched variant"}

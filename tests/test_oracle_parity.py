@@ -123,3 +123,66 @@ def test_cell_boundary_decision_is_attributed():
     print(rep["grad_rel_l2_vs_float64_raw"], rep["kink_rows"])
     assert rep["ok"], rep["failures"]
     assert [r["row"] for r in rep["kink_rows"]] == [row] and rep["kink_rows"][0]["matched"] == [f"cell:(0, 0):{shift}"]
+    m = rep["kink_rows"][0]["margins"][0]            # the margin that admitted it is reported: 2e-6 texels = ~0.5 ulp32 of the 63-texel extent
+    assert 1e-6 < m["texels"] < 4e-6 and m["ulp32_of_extent"] < 2.0 and m["window_texels"] == P.CELL_EPS
+    assert rep["windows"]["widest_margin_admitted"]["cell_texels"] == m["texels"]
+
+
+def test_cell_decision_outside_the_window_is_not_attributed():
+    """The same neighbouring-cell evaluation for a Gaussian 5e-4 texels from the boundary (round 4's window was 2e-3; a float32 evaluation of
+    the reference's coordinate formula lands within 3.3e-5): not rounding -- the row must stay unexplained and fail."""
+    pc, sd, leaves, gouts = _scene(n=400, seed=9)
+    flags, t, row = pc._deformation.args, 0.61, 55
+    aabb = sd["deformation_net.grid.aabb"]
+    with torch.no_grad():
+        c = (20.0 + 5e-4) / 63.0 * 2.0 - 1.0
+        leaves["_xyz"][row, 0] = (c + 1.0) / (2.0 / (aabb[1, 0] - aabb[0, 0])) + aabb[0, 0]
+    for g in gouts:
+        g[row] *= 300.0
+    ref = DO.backward_float64(sd, flags, {k: v.clone().requires_grad_(True) for k, v in leaves.items()}, t, gouts)
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    dec.cell_shift[(0, 0)] = torch.zeros(leaves["_xyz"].shape[0], dtype=torch.int64)
+    dec.cell_shift[(0, 0)][row] = -1
+    rep = P.attribute(sd, flags, leaves, t, gouts, _eval64(sd, flags, leaves, t, gouts, dec), ref)
+    assert not rep["ok"] and rep["n_kink_rows"] == 0 and rep["n_unexplained_rows"] == 1, rep
+
+
+def test_relu_margin_is_reported_and_bounded_by_its_window():
+    pc, sd, leaves, gouts = _scene()
+    flags, t, row, unit = pc._deformation.args, 0.37, 123, 17
+    _put_on_kink(sd, flags, leaves, t, row, unit)
+    for g in gouts:
+        g[row] *= 400.0
+    ref = DO.backward_float64(sd, flags, {k: v.clone().requires_grad_(True) for k, v in leaves.items()}, t, gouts)
+    dec = DO.KinkDecisions(leaves["_xyz"].shape[0])
+    dec.relu_flip["trunk"] = torch.zeros(leaves["_xyz"].shape[0], 128, dtype=torch.bool)
+    dec.relu_flip["trunk"][row, unit] = True
+    rep = P.attribute(sd, flags, leaves, t, gouts, _eval64(sd, flags, leaves, t, gouts, dec), ref)
+    m = rep["kink_rows"][0]["margins"][0]
+    assert m["window"] == P.RELU_WINDOW["trunk"] and 0.0 <= m["u32_units"] <= m["window"]
+    assert rep["windows"]["variant_tol"] == 1e-3 and rep["windows"]["relu_u32_units"] == P.RELU_WINDOW
+
+
+def test_windows_are_what_float32_rounding_justifies():
+    """The attribution windows are not free parameters: a float32 evaluation of the REFERENCE'S OWN arithmetic (the pinned oracle) lands this
+    far from its float64 evaluation (tools/parity_windows.py; 20 k .. 100 k Gaussians: trunk 119 .. 348, heads 39 .. 101 u32-units, coordinates
+    2.2 ulp32 of the axis extent = 8.3e-6 .. 4.1e-5 texels; profiles/r05_parity_windows_float32_vs_float64.txt).  Each window must cover the
+    measured maximum and stay within 4x of it."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from parity_windows import measure
+    worst_trunk = worst_head = worst_cell = 0.0
+    for cfg in ("dynerf_default", "hypernerf_default"):
+        m = measure(cfg, 20_000)
+        for layer, v in m["relu_u32_units"].items():
+            if layer == "trunk":
+                worst_trunk = max(worst_trunk, v["max"])
+            else:
+                worst_head = max(worst_head, v["max"])
+        worst_cell = max(worst_cell, max(v["max_texels"] for v in m["coordinate"].values()))
+        assert all(v["max_ulp32_of_extent"] < 4.0 for v in m["coordinate"].values())
+    print(f"float32 vs float64 of the reference arithmetic: trunk {worst_trunk:.0f}, heads {worst_head:.0f} u32-units, coordinate {worst_cell:.2e} texels")
+    assert worst_trunk <= P.RELU_WINDOW["trunk"] <= 4 * max(worst_trunk, 100.0)
+    assert worst_head <= P.RELU_WINDOW["head"] <= 4 * max(worst_head, 32.0)
+    assert worst_cell <= P.CELL_EPS <= 4 * max(worst_cell, 2.5e-5)
