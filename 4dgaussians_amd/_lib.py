@@ -102,6 +102,7 @@ SYMBOLS = {
     "fdgs_bin_prepare": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p]),
     "fdgs_bin_sort": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32]),
     "fdgs_render_fwd": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
+    "fdgs_raster_fwd_capacity": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdgs_raster_bwd": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, POINTER(RasterGrads)]),
     "fdgs_mark_visible": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdgs_geom_field": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),

@@ -116,10 +116,18 @@ __global__ void __launch_bounds__(256) scan_add_kernel(uint32_t* __restrict__ ds
 }
 
 // ---------------------------------------------------------------- radix histogram: hist[digit*nblocks + block]
+// `n_dev` (capacity mode, fdgs_raster_fwd_capacity): the key count lives on the device -- the launch is sized for the capacity `n`, the
+// kernel works on min(*n_dev, n) keys; blocks behind the end still publish their (zero) counters.
+__device__ __forceinline__ uint32_t live_count(const uint32_t* __restrict__ n_dev, uint32_t n) {
+    if (!n_dev) return n;
+    const uint32_t t = *n_dev;
+    return t < n ? t : n;
+}
 template <int ITEMS>
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
-                                                                  uint32_t* __restrict__ hist, int nblocks) {
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_dev, uint32_t n,
+                                                                  int shift, uint32_t mask, uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t h[RADIX];
+    n = live_count(n_dev, n);
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (SORT_THREADS * ITEMS);
@@ -140,8 +148,8 @@ template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint32_t* __restrict__ keys_out,
-                                                                     uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                                     const uint32_t* __restrict__ hist, int nblocks,
+                                                                     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_dev,
+                                                                     uint32_t n, int shift, const uint32_t* __restrict__ hist, int nblocks,
                                                                      const uint32_t* __restrict__ dtot) {
     __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counters
     __shared__ uint32_t lbase[RADIX];     // start of digit d inside the block-local regrouped array
@@ -152,6 +160,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
     __shared__ uint32_t wtmp[4];
     __shared__ uint32_t wtmp2[4];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    n = live_count(n_dev, n);
+    if (blockIdx.x * (uint32_t)CHUNK >= n) return;          // (capacity mode: a block behind the end; uniform over the workgroup)
 #pragma unroll
     for (int k = 0; k < 4; k++) wcnt[k][t] = 0;
     __syncthreads();
@@ -238,7 +248,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
 // LSD radix sort of n (key,val) pairs over bits [0,nbits). Ping-pongs between (k0,v0) and (k1,v1); returns which
 // buffer holds the result (0 or 1) through *result_in.
 int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, int nbits,
-                     uint32_t* hist, int nblocks, int debug, int* result_in, int items = SORT_ITEMS) {
+                     uint32_t* hist, int nblocks, int debug, int* result_in, int items = SORT_ITEMS, const uint32_t* n_dev = nullptr) {
     int cur = 0;
     if (n > 0) {
         const int npass = (nbits + RADIX_BITS - 1) / RADIX_BITS;
@@ -250,8 +260,8 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
             uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
             {
                 FDGS_TIMED("radix_hist", stream);
-                if (items == NSORT_ITEMS) hipLaunchKernelGGL(radix_hist_kernel<NSORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks);
-                else hipLaunchKernelGGL(radix_hist_kernel<SORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n, shift, mask, hist, nblocks);
+                if (items == NSORT_ITEMS) hipLaunchKernelGGL(radix_hist_kernel<NSORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n_dev, n, shift, mask, hist, nblocks);
+                else hipLaunchKernelGGL(radix_hist_kernel<SORT_ITEMS>, dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, n_dev, n, shift, mask, hist, nblocks);
             }
             FDGS_LAUNCH_CHECK("radix_hist", debug, stream);
             uint32_t* dtot = hist + (size_t)RADIX * nblocks;  // 256 digit totals live in the slack behind the counters
@@ -261,8 +271,8 @@ int radix_sort_pairs(hipStream_t stream, uint32_t* k0, uint32_t* v0, uint32_t* k
                 FDGS_TIMED("radix_scatter", stream);
 #define FDGS_SCATTER(B_)                                                                                                                  \
     do {                                                                                                                              \
-        if (items == NSORT_ITEMS) hipLaunchKernelGGL((radix_scatter_kernel<B_, NSORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot); \
-        else hipLaunchKernelGGL((radix_scatter_kernel<B_, SORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n, shift, hist, nblocks, dtot); \
+        if (items == NSORT_ITEMS) hipLaunchKernelGGL((radix_scatter_kernel<B_, NSORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n_dev, n, shift, hist, nblocks, dtot); \
+        else hipLaunchKernelGGL((radix_scatter_kernel<B_, SORT_ITEMS>), dim3(nblocks), dim3(SORT_THREADS), 0, stream, ki, vi, ko, vo, n_dev, n, shift, hist, nblocks, dtot); \
     } while (0)
                 switch (bits) {
                     case 1: FDGS_SCATTER(1); break; case 2: FDGS_SCATTER(2); break; case 3: FDGS_SCATTER(3); break; case 4: FDGS_SCATTER(4); break;
@@ -313,7 +323,8 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
                                                            const uint32_t* __restrict__ tiles, const uint2* __restrict__ rect,
                                                            const uint4* __restrict__ cullmask, const uint32_t* __restrict__ total,
                                                            int gx, uint32_t* __restrict__ pair_tile,
-                                                           uint32_t* __restrict__ pair_gid, uint32_t* __restrict__ ranges_zero, uint32_t ranges_n) {
+                                                           uint32_t* __restrict__ pair_gid, uint32_t* __restrict__ ranges_zero, uint32_t ranges_n,
+                                                           uint32_t cap /* capacity mode: pairs behind it are dropped (the FARTHEST: pairs come in depth order) */) {
     // (the per-tile ranges tile_ranges_kernel fills at the end of the stage: cleared here, on the way, instead of by a memset node)
     if (blockIdx.y == 0)
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ranges_n; k += gridDim.x * 256) ranges_zero[k] = 0u;
@@ -339,7 +350,7 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
     __syncthreads();
     const int first = blockIdx.x * 256;
     const uint32_t start = (first == 0) ? 0u : offsets_incl[first - 1];
-    const uint32_t stop = s_end[255];
+    const uint32_t stop = s_end[255] < cap ? s_end[255] : cap;
     (void)cnt;
     // gridDim.y workgroups share one block of 256 depth-consecutive Gaussians and interleave its pairs: the nearest Gaussians (the first
     // blocks) cover 60+ tiles each, five times the average.  Measured: 2 workgroups per block 0.036 ms, 1: 0.042, 4: 0.042, 8: 0.064 (the
@@ -367,8 +378,9 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
 
 // four pairs per thread (one 16-byte load + the two neighbours): a quarter of the threads of the one-pair form, whose 16.6 k workgroups of
 // three dependent 4-byte loads each were launch / latency bound (10.8 us for 17 MB)
-__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ pair_tile,
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __restrict__ n_dev, uint32_t R, const uint32_t* __restrict__ pair_tile,
                                                           uint2* __restrict__ ranges) {
+    R = live_count(n_dev, R);
     const uint32_t p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (p0 >= R) return;
     uint32_t t[6];          // t[0] = tile of pair p0 - 1, t[1..4] = pairs p0 .. p0 + 3, t[5] = pair p0 + 4
@@ -413,13 +425,15 @@ extern "C" int fdgs_binning_bytes(uint32_t R, int W, int H, size_t* bytes) {
     return FDGS_OK;
 }
 
-extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host) {
+// depth sort + offsets scan; the pair total goes to *num_rendered_host asynchronously.  wait = true: returns when it has arrived (the
+// reference's one blocking read-back), false: never blocks (capacity mode)
+static int bin_prepare_impl(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host, bool wait) {
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(geom && num_rendered_host, "geom/num_rendered_host is NULL");
     hipStream_t stream = (hipStream_t)stream_;
-    *num_rendered_host = 0;
-    if (p->P == 0) return FDGS_OK;
+    if (p->P == 0) { *num_rendered_host = 0; return FDGS_OK; }
+    if (wait) *num_rendered_host = 0;
     GeomLayout gl = geom_layout(p->P);
     // the total was accumulated by preprocess: start its read-back now, sort while it is in flight
     // one event per host thread, created on first use and kept (the ABI contract is one host thread per stream)
@@ -428,9 +442,9 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
     static thread_local hipEvent_t evs[FDGS_MAX_DEVICES] = {};
     const int dev_ = current_device_slot();
     hipEvent_t& ev = evs[dev_];
-    if (!ev) FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (wait && !ev) FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
-    FDGS_HIP_CHECK(hipEventRecord(ev, stream));
+    if (wait) FDGS_HIP_CHECK(hipEventRecord(ev, stream));
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(geom, gl.keys0), at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.keys1),
                           at<uint32_t>(geom, gl.ids1), (uint32_t)p->P, 32, at<uint32_t>(geom, gl.hist), gl.sort_blocks, p->debug,
@@ -455,14 +469,21 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { return fail(FDGS_E_HIP, "kernel %s failed: %s", "scan_tiles", hipGetErrorString(e_)); }
     }
-    hipError_t e = hipEventSynchronize(ev);
-    if (e != hipSuccess) return fail(FDGS_E_HIP, "%s failed: %s", "hipEventSynchronize", hipGetErrorString(e));
+    if (wait) {
+        hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) return fail(FDGS_E_HIP, "%s failed: %s", "hipEventSynchronize", hipGetErrorString(e));
+    }
     if (p->debug) FDGS_HIP_CHECK(hipStreamSynchronize(stream));
     return FDGS_OK;
 }
 
-extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img,
-                             uint32_t R) {
+extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host) {
+    return bin_prepare_impl(stream_, p, geom, num_rendered_host, true);
+}
+
+// pair expansion + tile sort + ranges.  from_device: R is the CAPACITY of `binning`; the kernels read the true pair count from the geom
+// buffer and work on min(true, capacity) pairs
+static int bin_sort_impl(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t R, bool from_device) {
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(geom && img && (binning || R == 0), "geom/binning/img is NULL");
@@ -474,15 +495,17 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
     }
     GeomLayout gl = geom_layout(p->P);
     BinLayout bl = bin_layout(R);
+    const uint32_t* n_dev = from_device ? at<uint32_t>(geom, gl.total) : nullptr;
     { FDGS_TIMED("expand_pairs", stream); hipLaunchKernelGGL(expand_pairs_kernel, dim3(cdiv(p->P, 256), 2), dim3(256), 0, stream, p->P, at<uint32_t>(geom, gl.ids0),
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
                        at<uint32_t>(geom, gl.total), il.gx,
-                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2)); }
+                       at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2),
+                       from_device ? R : 0xFFFFFFFFu); }
     FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.tile1),
                           at<uint32_t>(binning, bl.gid1), R, tile_bits(il.gx * il.gy), at<uint32_t>(binning, bl.hist), bl.sort_blocks,
-                          p->debug, &in);
+                          p->debug, &in, SORT_ITEMS, n_dev);
     if (rc) return rc;
     if (in != 0) {  // odd number of passes: bring the result back to buffer 0 (contract used by render + accessors)
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.tile1), (size_t)R * 4,
@@ -490,10 +513,26 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
         FDGS_HIP_CHECK(hipMemcpyAsync(at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.gid1), (size_t)R * 4,
                                       hipMemcpyDeviceToDevice, stream));
     }
-    { FDGS_TIMED("tile_ranges", stream); hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 1024)), dim3(256), 0, stream, R, at<uint32_t>(binning, bl.tile0),
+    { FDGS_TIMED("tile_ranges", stream); hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(R, 1024)), dim3(256), 0, stream, n_dev, R, at<uint32_t>(binning, bl.tile0),
                        at<uint2>(img, il.ranges)); }
     FDGS_LAUNCH_CHECK("tile_ranges", p->debug, stream);
     return FDGS_OK;
+}
+
+extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t R) {
+    return bin_sort_impl(stream_, p, geom, binning, img, R, false);
+}
+
+extern "C" int fdgs_raster_fwd_capacity(void* stream, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t capacity,
+                                        uint32_t* num_rendered_host, int32_t* radii, float* out_color, float* out_depth) {
+    FDGS_REQUIRE(capacity > 0 && binning, "capacity mode needs a binning buffer of fdgs_binning_bytes(capacity) bytes, capacity > 0");
+    int rc = fdgs_preprocess_fwd(stream, p, geom, radii);
+    if (rc) return rc;
+    rc = bin_prepare_impl(stream, p, geom, num_rendered_host, false);
+    if (rc) return rc;
+    rc = bin_sort_impl(stream, p, geom, binning, img, capacity, true);
+    if (rc) return rc;
+    return fdgs_render_fwd(stream, p, geom, binning, img, capacity, out_color, out_depth);
 }
 
 extern "C" int fdgs_geom_field(void* geom, int P, int which, void** ptr) {

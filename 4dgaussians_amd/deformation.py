@@ -342,6 +342,7 @@ class _FwdState:
 
 
 _pack_scratch = {}
+_net_cache = {}       # "k" -> (key, planes, mlp): the last network's normalised tensor lists (forward_impl)
 
 
 def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, rest, want_backward):
@@ -357,8 +358,20 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
     xyz_, scales_, rot_, op_ = c(xyz), c(scales), c(rotations), c(opacity)
     sh_a_, sh_b_ = c(sh_a), c(sh_b)
     t_ = None if t_tensor is None else c(t_tensor).reshape(-1)
-    planes = [_cl(p.detach()) for p in planes_in]
-    mlp = [c(m) for m in mlp_in]
+    # the network's 40 tensors: normalised (float32, planes channels-last) once per set of (tensor objects, storages) -- the optimizer
+    # steps them in place, so on every frame but the first this is 80 id() / data_ptr() calls instead of ~120 tensor ops
+    nkey = tuple(map(id, rest)) + tuple(t.data_ptr() for t in rest)
+    e = _net_cache.get("k")
+    if e is not None and e[0] == nkey:
+        planes, mlp = e[1], e[2]
+    else:
+        planes = [_cl(p.detach()) for p in planes_in]
+        mlp = [c(m) for m in mlp_in]
+        # (only cached when nothing had to be converted: a converted copy would go stale under an in-place optimizer step)
+        if all(a.data_ptr() == b.data_ptr() for a, b in zip(planes + mlp, rest)):
+            _net_cache["k"] = (nkey, planes, mlp)
+        else:
+            _net_cache.pop("k", None)
     N = xyz_.shape[0]
     st = _FwdState()
     st.keep = []

@@ -13,6 +13,10 @@ merge_many_4dgs.py:33,85-135 and scene/dataset_readers.py:485-508:
 All arithmetic runs in libfdgs.so (hand-written HIP for gfx950) through the C-ABI of include/fdgs.h; PyTorch only
 supplies device memory, the current HIP stream and autograd bookkeeping.  There is no CPU fallback.
 """
+import ctypes
+import os
+import threading
+import warnings
 from typing import NamedTuple
 
 import torch
@@ -42,15 +46,97 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
-_pinned = {}
-last_num_rendered = 0
+# ---- pair-count bookkeeping of the binning stage -------------------------------------------------------------------------------------
+# The reference's rasterizer reads the number of (tile, Gaussian) pairs back to the host in the middle of every forward (to size its
+# binning buffer) and the host waits for it.  Here that read-back is taken off the frame's critical path: once a pair count has been seen
+# for an image size, the binning buffer is sized for a CAPACITY predicted from the largest count seen so far (x CAPACITY_SLACK) and the
+# whole forward is ONE non-blocking C call (fdgs_raster_fwd_capacity); the true count arrives in pinned host memory some time later and
+# is looked at when the NEXT frame starts: it feeds the predictor, and a count above the capacity (the farthest pairs of that frame were
+# dropped) raises a RuntimeWarning, is counted in `capacity_overflows`, and enlarges the capacity from then on.  The first frame of an image
+# size -- and every frame with BINNING = "exact" (FDGS_BINNING=exact) -- takes the reference's blocking path and is exact by construction.
+# State is per host thread (threading.local): one thread drives a stream, as include/fdgs.h requires.
+BINNING = os.environ.get("FDGS_BINNING", "auto")
+CAPACITY_SLACK = 1.3
+capacity_overflows = 0
+_SENTINEL = 0xFFFFFFFF
+_RING = 64
+_tls = threading.local()
+_seen = {}            # (device index, W, H) -> [largest pair count seen, P it was seen at]
+_size_cache = {}      # ("geom", P) / ("img", W, H) / ("bin", R) -> bytes
 
 
-def _pinned_u32(device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    if key not in _pinned:
-        _pinned[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
-    return _pinned[key]
+class PairCount:
+    """The pair count of one forward: known at once on the exact path, later on the capacity path (`value()` waits for it)."""
+    __slots__ = ("addr", "capacity", "key", "P", "R", "stream")
+
+    def poll(self):
+        if self.R is None:
+            v = ctypes.c_uint32.from_address(self.addr).value
+            if v != _SENTINEL:
+                self.R = v
+                _note_count(self)
+        return self.R
+
+    def value(self):
+        if self.poll() is None:
+            self.stream.synchronize()
+            self.poll()
+        return self.R
+
+
+def _note_count(c):
+    global capacity_overflows
+    e = _seen.get(c.key)
+    if e is None or abs(c.P - e[1]) > 0.25 * max(e[1], 1):      # first frame of this image size, or another model: start over
+        _seen[c.key] = [c.R, c.P]
+    else:
+        e[0], e[1] = max(e[0], c.R), c.P
+    if c.capacity is not None and c.R > c.capacity:
+        capacity_overflows += 1
+        warnings.warn(f"fdgs rasterizer: a frame listed {c.R} (tile, Gaussian) pairs but its binning buffer was sized for {c.capacity}: the "
+                      f"farthest {c.R - c.capacity} pairs of that frame were dropped; the capacity grows from the next frame on "
+                      "(FDGS_BINNING=exact restores the blocking exact path)", RuntimeWarning, stacklevel=3)
+
+
+def _thread_state(dev):
+    st = getattr(_tls, "st", None)
+    if st is None:
+        st = _tls.st = {"ring": {}, "pending": [], "last": None}
+    ring = st["ring"].get(dev.index)
+    if ring is None:
+        ring = st["ring"][dev.index] = [_pinned_words(_RING), 0]
+    return st, ring
+
+
+def _pinned_words(n):
+    return torch.zeros(n, dtype=torch.int32).pin_memory()
+
+
+def _current_stream(dev):
+    return torch.cuda.current_stream(dev)
+
+
+def _bytes(L, kind, *args):
+    key = (kind,) + args
+    v = _size_cache.get(key)
+    if v is None:
+        nbytes = _lib.c_size_t()
+        if kind == "geom":
+            check(L.fdgs_geom_bytes(args[0], nbytes))
+        elif kind == "img":
+            check(L.fdgs_img_bytes(args[0], args[1], nbytes))
+        else:
+            check(L.fdgs_binning_bytes(args[0], args[1], args[2], nbytes))
+        if len(_size_cache) > 256:
+            _size_cache.clear()
+        v = _size_cache[key] = nbytes.value
+    return v
+
+
+def last_num_rendered():
+    """Pair count of this thread's most recent forward (diagnostics; waits for the frame if its count has not arrived yet)."""
+    st = getattr(_tls, "st", None)
+    return 0 if st is None or st["last"] is None else int(st["last"].value())
 
 
 def _f32(t, device):
@@ -68,8 +154,13 @@ def _none_if_empty(t):
 
 
 class RasterState:
-    """Buffers one forward pass leaves behind for its backward (the reference's geom/binning/img buffers)."""
-    __slots__ = ("params", "geom", "binning", "img", "num_rendered", "keep", "visibility")
+    """Buffers one forward pass leaves behind for its backward (the reference's geom/binning/img buffers).  `capacity` = the pair count
+    the binning buffer is laid out for (what the C calls take as num_rendered); `num_rendered` = the true count (waits for it if needed)."""
+    __slots__ = ("params", "geom", "binning", "img", "capacity", "count", "keep", "visibility")
+
+    @property
+    def num_rendered(self):
+        return int(self.count.value())
 
 
 def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None):
@@ -101,11 +192,8 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     p.bg, p.viewmatrix, p.projmatrix, p.campos = ptr(bg), ptr(view), ptr(proj), ptr(campos)
     p.means3D, p.shs, p.colors_precomp, p.opacities = ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities)
     p.scales, p.rotations, p.cov3D_precomp = ptr(scales), ptr(rotations), ptr(cov3D_precomp)
-    nbytes = _lib.c_size_t()
-    check(L.fdgs_geom_bytes(P, nbytes))
-    geom = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    check(L.fdgs_img_bytes(W, H, nbytes))
-    img = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    geom = torch.empty(_bytes(L, "geom", P), dtype=torch.uint8, device=dev)
+    img = torch.empty(_bytes(L, "img", W, H), dtype=torch.uint8, device=dev)
     if out is not None:
         color, radii, depth = out
     else:
@@ -115,18 +203,37 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     vis = torch.empty(P, dtype=torch.bool, device=dev)       # radii > 0, written by the projection kernel (no elementwise launch)
     p.visibility = ptr(vis)
     st = stream_ptr()
-    check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
-    host = _pinned_u32(dev)
-    check(L.fdgs_bin_prepare(st, p, ptr(geom), _lib.c_void_p(host.data_ptr())))
-    R = int(host.item()) & 0xFFFFFFFF
-    global last_num_rendered
-    last_num_rendered = R                 # (diagnostics: bench.py reports it per scene)
-    check(L.fdgs_binning_bytes(R, W, H, nbytes))
-    binning = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    check(L.fdgs_bin_sort(st, p, ptr(geom), ptr(binning), ptr(img), R))
-    check(L.fdgs_render_fwd(st, p, ptr(geom), ptr(binning), ptr(img), R, ptr(color), ptr(depth)))
+    tstate, ring = _thread_state(dev)
+    pending = tstate["pending"]
+    if pending:           # counts of earlier frames that have arrived meanwhile: feed the predictor (never waits)
+        tstate["pending"] = pending = [c for c in pending if c.poll() is None]
+    key = (dev.index, W, H)
+    seen = _seen.get(key)
+    cnt = PairCount()
+    cnt.key, cnt.P, cnt.R, cnt.stream = key, P, None, None
+    slot = ring[1] = (ring[1] + 1) % _RING
+    cnt.addr = ring[0].data_ptr() + 4 * slot
+    if BINNING != "exact" and seen is not None and P > 0 and abs(P - seen[1]) <= 0.25 * max(seen[1], 1) and len(pending) < _RING - 2:
+        cap = (int(seen[0] * CAPACITY_SLACK) + 8192) // 4096 * 4096
+        cnt.capacity = cap
+        cnt.stream = _current_stream(dev)
+        ctypes.c_uint32.from_address(cnt.addr).value = _SENTINEL
+        binning = torch.empty(_bytes(L, "bin", cap, W, H), dtype=torch.uint8, device=dev)
+        check(L.fdgs_raster_fwd_capacity(st, p, ptr(geom), ptr(binning), ptr(img), cap, _lib.c_void_p(cnt.addr), ptr(radii), ptr(color), ptr(depth)))
+        pending.append(cnt)
+    else:
+        check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
+        check(L.fdgs_bin_prepare(st, p, ptr(geom), _lib.c_void_p(cnt.addr)))          # (blocks until the count is in host memory)
+        cap = ctypes.c_uint32.from_address(cnt.addr).value
+        cnt.capacity = None
+        cnt.R = cap
+        _note_count(cnt)
+        binning = torch.empty(_bytes(L, "bin", cap, W, H), dtype=torch.uint8, device=dev)
+        check(L.fdgs_bin_sort(st, p, ptr(geom), ptr(binning), ptr(img), cap))
+        check(L.fdgs_render_fwd(st, p, ptr(geom), ptr(binning), ptr(img), cap, ptr(color), ptr(depth)))
+    tstate["last"] = cnt
     state = RasterState()
-    state.params, state.geom, state.binning, state.img, state.num_rendered = p, geom, binning, img, R
+    state.params, state.geom, state.binning, state.img, state.capacity, state.count = p, geom, binning, img, cap, cnt
     state.visibility = vis
     state.keep = (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, bg, view, proj, campos)
     return color, radii, depth, state
@@ -152,7 +259,7 @@ def rasterize_backward(state, grad_color, grad_depth=None):
     g.dL_dmeans2D, g.dL_dmeans3D, g.dL_dopacity = ptr(out["means2D"]), ptr(out["means3D"]), ptr(out["opacities"])
     g.dL_dcolors, g.dL_dsh, g.dL_dscales = ptr(out["colors"]), ptr(out["shs"]), ptr(out["scales"])
     g.dL_drotations, g.dL_dcov3D, g.scratch_acc = ptr(out["rotations"]), ptr(out["cov3D"]), ptr(scratch)
-    check(L.fdgs_raster_bwd(stream_ptr(), p, ptr(state.geom), ptr(state.binning), ptr(state.img), state.num_rendered, g))
+    check(L.fdgs_raster_bwd(stream_ptr(), p, ptr(state.geom), ptr(state.binning), ptr(state.img), state.capacity, g))
     return out
 
 

@@ -78,7 +78,7 @@ class _FusedRenderFunction(torch.autograd.Function):
             epi.zero_fill, epi.zero_floats = b.zero_range
         g.deform_epilogue = _lib.ctypes.pointer(epi)
         _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
-                                     rstate.num_rendered, g))
+                                     rstate.capacity, g))
         b.g.packed_rows_ready = epi.tile_flags + 1
         grads = _deformation.backward_run(st, b)       # (d_xyz, d_sc, d_rot, d_op, d_sha, d_shb, None [time], None [aabb], planes..., mlp...)
         return (None, None, None, g_means2D) + grads[:6] + grads[7:]
@@ -150,7 +150,7 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             epi.tile_flags = _tile_flags()
             g.deform_epilogue = _lib.ctypes.pointer(epi)
             _lib.check(L.fdgs_raster_bwd(_lib.stream_ptr(), p, _lib.ptr(rstate.geom), _lib.ptr(rstate.binning), _lib.ptr(rstate.img),
-                                         rstate.num_rendered, g))
+                                         rstate.capacity, g))
             # this view's deformation backward: same output pointers and scratch (stream-ordered reuse), its own saved activations
             b.g.out_scales, b.g.out_rotations, b.g.out_opacity = _lib.ptr(saved[3 * v]), _lib.ptr(saved[3 * v + 1]), _lib.ptr(saved[3 * v + 2])
             b.g.rot_norm, b.g.saved = _lib.ptr(st.o_norm), _lib.ptr(st.saved_act)

@@ -385,7 +385,7 @@ def run(args, make_step=None):
         extras[other + "_scene"] = {"frames_per_s": world * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
                                     "what": f"the same workload on synthetic scene {other!r} (bench.py --scene {other}): " +
                                             ("three thin translucent spheres, opacity U(0.02, 0.2), half-size splats" if other == "shell" else "SURVEY 8d's cube"),
-                                    "num_rendered": int(fdgs.rasterizer.last_num_rendered),
+                                    "num_rendered": int(fdgs.rasterizer.last_num_rendered()),
                                     "backward_live_tiles": {"live": lt[0], "tiles": lt[1], "frac": round(lt[0] / max(lt[1], 1), 4)},
                                     "deform_bwd_data_frac_of_f32_mfma_peak": (d2_flops / (ks["deform_bwd_data"]["avg_ms"] * 1e-3) / MFMA_F32_PEAK) if "deform_bwd_data" in ks else None,
                                     "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"])[:9]}}

@@ -103,6 +103,14 @@ int fdgs_bin_sort(void* stream, const fdgs_raster_params* p, void* geom, void* b
                   uint32_t num_rendered);
 
 /* Stage 4: front-to-back alpha blending per 16x16 tile. out_color [3,H,W], out_depth [1,H,W]. */
+/* Capacity mode (ABI 4): stages 1-4 in ONE call and WITHOUT a host synchronisation.  `binning` holds fdgs_binning_bytes(capacity)
+ * bytes for a pair count the caller predicts (e.g. 1.3 x the largest count it has seen); the true count stays on the device -- the kernels
+ * work on min(true, capacity) pairs -- and is copied to *num_rendered_host (pinned host memory) asynchronously: pre-set the word to
+ * 0xFFFFFFFF and read it once it changed (or after the stream passed this call).  true > capacity means the FARTHEST pairs of this frame
+ * were dropped (pairs are emitted in depth order): render again with a larger capacity.  The buffers are laid out for `capacity`: pass
+ * `capacity` as num_rendered to fdgs_raster_bwd / fdgs_binning_field.  P = 0 writes 0 to the word immediately. */
+int fdgs_raster_fwd_capacity(void* stream, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t capacity,
+                             uint32_t* num_rendered_host, int32_t* radii, float* out_color, float* out_depth);
 int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom, const void* binning, void* img,
                     uint32_t num_rendered, float* out_color, float* out_depth);
 

@@ -57,7 +57,7 @@ def _binning(state, which, dev):
 
     def f():
         out = ctypes.c_void_p()
-        assert L.fdgs_binning_field(ctypes.c_void_p(state.binning.data_ptr()), state.num_rendered, state.params.W,
+        assert L.fdgs_binning_field(ctypes.c_void_p(state.binning.data_ptr()), state.capacity, state.params.W,      # (the buffer is LAID OUT for the capacity)
                                     state.params.H, which, ctypes.byref(out)) == 0
         return out.value
     return _dev_field(f, (state.num_rendered,), torch.int32, dev).view(np.uint32)
@@ -357,3 +357,73 @@ def test_blending_kernel_forms_agree(with_depth, monkeypatch):
         assert np.abs(c - c0).max() <= 1e-6 and np.abs(d - d0).max() <= 1e-5, name       # (forward forms: same arithmetic, fma order only)
         for k in g0:
             assert rel_l2(g[k], g0[k]) < 5e-6, (name, k, rel_l2(g[k], g0[k]))
+
+
+def test_capacity_mode_equals_the_blocking_exact_path(monkeypatch):
+    """rasterize_forward sizes the binning buffer from a predicted pair count once it has seen one for the image size and then runs the whole
+    forward as ONE non-blocking C call (fdgs_raster_fwd_capacity: the kernels read the true count on the device).  Same image, depth, radii
+    and per-pixel bookkeeping bit for bit, same sorted lists and ranges, same gradients as the blocking exact path."""
+    dev = torch.device("cuda:0")
+    R = _mod().rasterizer
+    sc = raster_scene(30000, 640, 480, seed=21, scale_boost=1.5)
+    rng = np.random.default_rng(5)
+    wc = torch.tensor(rng.standard_normal((3, 480, 640)).astype(np.float32), device=dev)
+    outs = {}
+    for mode in ("exact", "auto"):
+        monkeypatch.setattr(R, "BINNING", mode)
+        if mode == "auto":
+            assert (dev.index, 640, 480) in R._seen           # the exact frame above fed the predictor
+        t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        color, radii, depth, st = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
+                                                      t["rotations"], None)
+        if mode == "auto":
+            assert st.count.capacity is not None and st.capacity >= st.num_rendered > 0 and st.capacity % 4096 == 0
+        else:
+            assert st.count.capacity is None and st.capacity == st.num_rendered
+        g = R.rasterize_backward(st, wc)
+        torch.cuda.synchronize()
+        n = st.num_rendered
+        outs[mode] = dict(color=color.clone(), radii=radii.clone(), depth=depth.clone(), n=n, gid=_binning(st, 0, dev)[:n], tile=_binning(st, 1, dev)[:n],
+                          ranges=_img(st, 2, (((480 + 15) // 16) * ((640 + 15) // 16), 2), torch.int32, dev),
+                          ncontrib=_img(st, 1, (480, 640), torch.int32, dev), grads={k: v.clone() for k, v in g.items() if v is not None})
+    a, b = outs["exact"], outs["auto"]
+    assert a["n"] == b["n"]
+    for k in ("color", "radii", "depth"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("gid", "tile", "ranges", "ncontrib"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in a["grads"]:
+        assert rel_l2(b["grads"][k].cpu().numpy(), a["grads"][k].cpu().numpy()) < 5e-6, k
+
+
+def test_capacity_overflow_is_detected_and_the_capacity_grows(monkeypatch):
+    """A frame that lists more pairs than its binning buffer was sized for drops its FARTHEST pairs (never writes out of bounds), is reported
+    with a RuntimeWarning when its count arrives, counted in `capacity_overflows`, and the next frame's capacity covers it."""
+    import warnings
+    dev = torch.device("cuda:0")
+    R = _mod().rasterizer
+    sc = raster_scene(20000, 416, 304, seed=22, scale_boost=2.0)
+    monkeypatch.setattr(R, "BINNING", "auto")
+    t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    args = (t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
+    key = (dev.index, 416, 304)
+    R._seen.pop(key, None)
+    color0, radii0, depth0, st0 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)          # first frame of this size: exact
+    true_n = st0.num_rendered
+    assert st0.count.capacity is None and true_n > 40000
+    R._seen[key] = [true_n // 4, 20000]                                                                 # a predictor that is far too low
+    before = R.capacity_overflows
+    color1, radii1, depth1, st1 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)
+    assert st1.capacity < true_n
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert st1.num_rendered == true_n                                                               # (waits for the count, which reports the overflow)
+    assert R.capacity_overflows == before + 1 and any(issubclass(x.category, RuntimeWarning) for x in w)
+    torch.cuda.synchronize()
+    assert torch.equal(radii1, radii0)
+    assert bool(torch.isfinite(color1).all()) and float((color1 - color0).abs().max()) > 0.0            # far pairs are missing, nothing else broke
+    n_kept = int(_img(st1, 2, (((304 + 15) // 16) * ((416 + 15) // 16), 2), torch.int32, dev)[:, 1].max())
+    assert n_kept <= st1.capacity
+    color2, radii2, depth2, st2 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)          # the predictor has learnt
+    assert st2.capacity >= true_n and st2.num_rendered == true_n
+    assert torch.equal(color2, color0) and torch.equal(depth2, depth0)

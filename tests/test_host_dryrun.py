@@ -26,6 +26,8 @@ class _FakeLib:
                 a[-1].value = 4096
             elif name == "fdgs_bin_prepare":
                 ctypes.cast(a[3], ctypes.POINTER(ctypes.c_uint32))[0] = 7
+            elif name == "fdgs_raster_fwd_capacity":      # (the device would deliver the count later; the fake delivers it at once)
+                ctypes.cast(a[6], ctypes.POINTER(ctypes.c_uint32))[0] = 7
             elif name == "fdgs_deform_bwd_live_tiles":
                 for i in range(4):
                     a[3][i] = 1
@@ -44,7 +46,10 @@ def fake(monkeypatch):
     monkeypatch.setattr(fdgs._lib, "stream_ptr", lambda: ctypes.c_void_p(0))
     monkeypatch.setattr(fdgs.rasterizer, "stream_ptr", lambda: ctypes.c_void_p(0))
     monkeypatch.setattr(fdgs.deformation, "stream_ptr", lambda: ctypes.c_void_p(0), raising=False)
-    monkeypatch.setattr(fdgs.rasterizer, "_pinned_u32", lambda dev: torch.zeros(1, dtype=torch.int32))
+    monkeypatch.setattr(fdgs.rasterizer, "_pinned_words", lambda n: torch.zeros(n, dtype=torch.int32))
+    monkeypatch.setattr(fdgs.rasterizer, "_current_stream", lambda dev: type("S", (), {"synchronize": lambda self: None})())
+    monkeypatch.setattr(fdgs.rasterizer, "_tls", __import__("threading").local())
+    monkeypatch.setattr(fdgs.rasterizer, "_seen", {})
     # rasterize_forward / forward_impl refuse non-HIP tensors: the dry run claims to be one
     monkeypatch.setattr(fdgs.rasterizer, "_is_hip_device", lambda dev: True)
     monkeypatch.setattr(fdgs.deformation, "_is_hip_device", lambda dev: True)
