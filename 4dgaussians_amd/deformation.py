@@ -161,27 +161,41 @@ def _head_on(args):
     return [0 if getattr(args, f) else 1 for f in HEAD_FLAGS]
 
 
-_collect_cache = {}     # id(net) -> (weakref(net), planes, mlp)
-
-
 def _collect(net):
     """Flat, ordered tensor list handed to the autograd Function (must match _DeformFunction.backward).
-    The walk through the module tree (~90 nn.Module.__getattr__ / container lookups, 0.1 ms per frame on the host) is done once per module:
-    the Parameter OBJECTS of a deform_network stay what they are (optimizers, load_state_dict and .to() change them in place); the cached
-    list is checked against the first plane and the last MLP parameter on every call and rebuilt when either was replaced."""
-    e = _collect_cache.get(id(net))
+    The walk through the module tree (~90 nn.Module.__getattr__ / container lookups, 0.1 ms per frame on the host) is done once per module
+    and kept ON the module (it dies with it; nothing else holds the Parameters).  Every call re-validates EVERY entry with plain dict
+    look-ups: each cached (container, key) slot must still hold the cached object -- the 40 Parameters in their owners' `_parameters`, and
+    the modules on the way down in their parents' `_modules` -- so a replaced Parameter (`load_state_dict(assign=True)`, `lin.weight = ...`),
+    a swapped head Sequential or a re-created grid level all rebuild the list."""
+    e = net.__dict__.get("_fdgs_collect")
+    if e is not None:
+        for owner_dict, key, obj in e[0]:
+            if owner_dict.get(key) is not obj:
+                break
+        else:
+            return e[1], e[2]
     dn = net.deformation_net
-    if e is not None and e[0]() is net and e[1][0] is dn.grid.grids[0][0] and e[2][-1] is getattr(dn, HEAD_NAMES[-1])[3].bias:
-        return e[1], e[2]
-    planes = [dn.grid.grids[l][k] for l in range(len(dn.grid.grids)) for k in range(6)]
-    mlp = [dn.feature_out[0].weight, dn.feature_out[0].bias]
+    slots = [(net._modules, "deformation_net", dn), (dn._modules, "grid", dn.grid), (dn.grid._modules, "grids", dn.grid.grids),
+             (dn._modules, "feature_out", dn.feature_out), (dn.feature_out._modules, "0", dn.feature_out[0])]
+    planes = []
+    for l in range(len(dn.grid.grids)):
+        level = dn.grid.grids[l]
+        slots.append((dn.grid.grids._modules, str(l), level))
+        for k in range(6):
+            planes.append(level[k])
+            slots.append((level._parameters, str(k), level[k]))
+    lin0 = dn.feature_out[0]
+    mlp = [lin0.weight, lin0.bias]
+    slots += [(lin0._parameters, "weight", lin0.weight), (lin0._parameters, "bias", lin0.bias)]
     for name in HEAD_NAMES:
         seq = getattr(dn, name)
-        mlp += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
-    import weakref
-    if len(_collect_cache) >= 16:
-        _collect_cache.clear()
-    _collect_cache[id(net)] = (weakref.ref(net), planes, mlp)
+        slots.append((dn._modules, name, seq))
+        for idx in ("1", "3"):
+            lin = seq._modules[idx]
+            slots += [(seq._modules, idx, lin), (lin._parameters, "weight", lin.weight), (lin._parameters, "bias", lin.bias)]
+            mlp += [lin.weight, lin.bias]
+    net.__dict__["_fdgs_collect"] = (slots, planes, mlp)
     return planes, mlp
 
 

@@ -212,13 +212,20 @@ _zero_pool = {}
 def _zero_leaf(like):
     """A fresh LEAF of zeros shaped like `like` without a fill launch per frame: every frame's leaf is a detached alias of one cached,
     never-written zero buffer per (shape, dtype, device) -- the values are only ever read (the rasterizer ignores them, as the reference's
-    does), the gradient arrives in the leaf's own `.grad`."""
+    does), the gradient arrives in the leaf's own `.grad`.  READ-ONLY by contract: `viewspace_points` of every frame shares this storage, so
+    an in-place write through it (`.data`, an op under no_grad) would show up in every later frame's tensor (the reference's is a fresh
+    `zeros_like` per frame; nothing in the reference writes to it, train.py:223-225 only reads `.grad`)."""
     key = (tuple(like.shape), like.dtype, like.device)
     z = _zero_pool.get(key)
     if z is None:
         if len(_zero_pool) > 8:
             _zero_pool.clear()
-        z = _zero_pool[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+        # (a normal tensor whatever mode the first caller is in: under torch.inference_mode() it would be an inference tensor and the
+        # requires_grad_ of a later training frame would raise)
+        with torch.inference_mode(False), torch.no_grad():
+            z = _zero_pool[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    if torch.is_inference_mode_enabled():
+        return z.detach()                       # (no autograd inside inference mode: nothing will ask for a gradient)
     return z.detach().requires_grad_(True)
 
 

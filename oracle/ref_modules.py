@@ -88,3 +88,38 @@ def load():
     ns.eval_sh, ns.setup_camera, ns.graphics_utils = su.eval_sh, sc.setup_camera, gu
     ns.render_module = gr
     return ns
+
+
+def load_train():
+    """`load()` plus the reference's train-step objects (round 5):
+        GaussianModel        scene/gaussian_model.py:27   (training_setup :165, update_learning_rate :197, add_densification_stats :516, densify :495,
+                                                           prune :481, reset_opacity :269, compute_regulation :576)
+        l1_loss, ssim        utils/loss_utils.py:20,40    psnr  utils/image_utils.py:17    get_expon_lr_func  utils/general_utils.py:37
+    Its imports of open3d / plyfile / lpips (point-cloud files, the perceptual loss: not on this path) are stubbed; `simple_knn._C` resolves
+    to this repository's shim package (csrc/knn.hip)."""
+    ns = load()
+    for name, attrs in (("open3d", {}), ("plyfile", {"PlyData": object, "PlyElement": object}), ("lpips", {})):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                m = types.ModuleType(name)
+                for k, v in attrs.items():
+                    setattr(m, k, v)
+                sys.modules[name] = m
+    knn = importlib.import_module("simple_knn._C")
+    assert os.path.dirname(os.path.dirname(os.path.abspath(knn.__file__))) == ROOT, "simple_knn does not resolve to the shim"
+    for name in ("general_utils", "system_utils", "loss_utils", "image_utils"):
+        if f"utils.{name}" not in sys.modules:
+            _pyc(f"utils.{name}", f"utils/{name}.pyc")
+    if "scene.regulation" not in sys.modules:
+        _pyc("scene.regulation", "scene/regulation.pyc")
+    gm = sys.modules.get("scene.gaussian_model")
+    if gm is None or getattr(gm, "__fdgs_stub__", False):
+        sys.modules.pop("scene.gaussian_model", None)
+        gm = _pyc("scene.gaussian_model", "scene/gaussian_model.pyc")
+    ns.GaussianModel = gm.GaussianModel
+    ns.l1_loss, ns.ssim = sys.modules["utils.loss_utils"].l1_loss, sys.modules["utils.loss_utils"].ssim
+    ns.psnr = sys.modules["utils.image_utils"].psnr
+    ns.get_expon_lr_func = sys.modules["utils.general_utils"].get_expon_lr_func
+    return ns

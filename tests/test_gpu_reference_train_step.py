@@ -1,0 +1,45 @@
+"""The reference's own train step (GaussianModel.training_setup / update_learning_rate / compute_regulation / add_densification_stats /
+densify / prune / reset_opacity + render() + l1_loss + torch.optim.Adam, byte-compiled from /root/reference) executed on the MI355X over this
+repository's `diff_gaussian_rasterization` / `simple_knn` shims, against the same 200 iterations through the drop-ins (fdgs.render,
+fdgs.deform_network, fdgs.losses, fdgs.compute_regulation, fdgs.densify.*, fdgs.FusedAdam) from identical state: train.py:180-292."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import train_step_proxy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_train_step_over_the_shims_matches_the_drop_ins():
+    from oracle import ref_modules
+    if not ref_modules.available() or not os.path.isfile(os.path.join(ref_modules.OUT, "scene", "gaussian_model.pyc")):
+        pytest.skip("oracle/_ref not built (python -m oracle.build_ref where /root/reference exists)")
+    rep = train_step_proxy.run(iters=200, interval=50)
+    out = os.environ.get("FDGS_TRAIN_STEP_JSON")
+    if out:
+        json.dump(rep, open(out, "w"))
+    for ev in rep["events"]:
+        print({k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in ev.items()})
+    ma, mb = float(np.mean(rep["final_psnr_A"])), float(np.mean(rep["final_psnr_B"]))
+    print(f"densification threshold {rep['threshold']:.3e}; N {rep['events'][0]['N_before'][0]} -> {rep['N_final']}; resyncs {rep['resyncs']}; "
+          f"PSNR start {rep['psnr_A'][0]:.2f} dB -> reference loop {ma:.3f} dB, drop-ins {mb:.3f} dB (diff {mb - ma:+.4f}); max per-iteration drift {rep['drift']:.4f} dB")
+    assert rep["optimizer_B"] == "FusedAdam"
+    assert len(rep["events"]) == 4 and rep["N_final"][0] > rep["events"][0]["N_before"][0]          # the set actually grew
+    assert any(ev["plan_B"][1] > 0 for ev in rep["events"]) and any(ev["plan_B"][2] > 0 for ev in rep["events"])   # clones AND splits happened
+    for ev in rep["events"]:
+        if ev["N_before"][0] == ev["N_before"][1]:
+            # the statistics the densification decides on, accumulated over the 50 iterations since the last event
+            assert ev["accum_rel_l2"] < 2e-3 and ev["denom_mismatch_frac"] < 2e-3 and ev["max_radii2D_mismatch_frac"] < 5e-3, ev
+        if ev["N_after"][0] != ev["N_after"][1]:
+            # a different N is only acceptable for Gaussians that sat ON the threshold in the reference leg (|g / threshold - 1| < 1 %), all named
+            assert 0 < ev.get("n_differently_selected", 0) <= 3 and all(abs(m) < 1e-2 for _, m in ev["differently_selected"]), ev
+        else:
+            assert ev["table_equal"] and ev["xyz_rel_l2_after"] < 5e-3, ev
+    first = rep["events"][0]
+    assert first["N_after"][0] == first["N_after"][1], first            # from identical state, the first densification agrees exactly
+    assert abs(mb - ma) < 0.05                                          # north_star: PSNR within 0.05 dB
+    assert max(abs(a - b) for a, b in zip(rep["final_psnr_A"], rep["final_psnr_B"])) < 0.15
+    assert np.abs(np.array(rep["psnr_A"][:40]) - np.array(rep["psnr_B"][:40])).max() < 0.01

@@ -121,3 +121,24 @@ def test_gradient_arena_layout_tiles_the_arena_without_overlap():
     seq[3].bias = torch.nn.Parameter(seq[3].bias.detach().clone())
     c = d._collect(net)
     assert c[1] is not a[1] and c[1][-1] is seq[3].bias
+    # an INTERIOR parameter, a whole head and a grid level replaced: each is noticed (every cached slot is re-validated on every call)
+    dn = net.deformation_net
+    lin = getattr(dn, d.HEAD_NAMES[1])[1]
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone())
+    e = d._collect(net)
+    assert e[1] is not c[1] and any(t is lin.weight for t in e[1])
+    import copy
+    setattr(dn, d.HEAD_NAMES[2], copy.deepcopy(getattr(dn, d.HEAD_NAMES[2])))
+    f = d._collect(net)
+    assert f[1] is not e[1] and any(t is getattr(dn, d.HEAD_NAMES[2])[3].weight for t in f[1])
+    dn.grid.grids[0] = copy.deepcopy(dn.grid.grids[0])
+    g = d._collect(net)
+    assert g[0] is not f[0] and g[0][0] is dn.grid.grids[0][0]
+    assert d._collect(net)[0] is g[0]                      # ... and an untouched module hits the cache
+    # the cache lives on the module: nothing global keeps a deleted model's Parameters alive
+    import gc
+    import weakref
+    w = weakref.ref(net.deformation_net.grid.grids[0][0])
+    del net, a, b, c, e, f, g, dn, lin, seq
+    gc.collect()
+    assert w() is None
