@@ -71,8 +71,10 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
           f"depth mean abs {dmean:.2e}  radii mismatch {mism:.2e}")
     assert psnr >= 80.0 and d.mean() < 2e-6
     # measured: 18 .. 958 such pixels (0.003 % .. 0.07 %); each is ONE alpha >= 1/255 decision taken the other way for an entry
-    # whose alpha sits within rounding of the threshold, which moves a pixel by at most alpha * T * colour <= ~1/255
-    assert n_flip <= int(2e-3 * H * W) and d.max() <= 1.1 / 255.0, (n_flip, float(d.max()))
+    # whose alpha sits within rounding of the threshold, which moves a pixel channel by at most alpha * T * colour <= colour / 255 -- the SH colour
+    # max(0, sh + 0.5) has no upper clamp (utils/sh_utils.py:113), so the bound is the largest colour of a visible Gaussian, not 1
+    cmax = max(1.0, float(o.field("rgb")[o.radii > 0].max()))
+    assert n_flip <= int(2e-3 * H * W) and d.max() <= 1.1 * cmax / 255.0, (n_flip, float(d.max()), cmax)
     assert dmean < 2e-5 and mism < 2e-4
     named = dict(pc.named_parameters())
     means2D_ref = gref.pop("__means2D")
