@@ -106,16 +106,9 @@ def _restructure(pc, mode, *, grad_threshold=0.0, dense_size=0.0, min_opacity=0.
     # (a forgotten reduction, a threshold comparison that fell the other way on one rank, or one rank arriving with its own `normals`
     # would otherwise leave the ranks that do reach the broadcast below blocked until the process-group timeout)
     import torch.distributed as dist
+    from . import parallel as _parallel
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if multi:
-        mine = torch.tensor([kept, clones, splits, 1 if normals is None else 0], device=dev, dtype=torch.int64)
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
-            raise RuntimeError(f"densify: ranks disagree on the plan (kept, clones, splits, samples-drawn-here): min {lo.tolist()} max {hi.tolist()}, "
-                               f"this rank {mine.tolist()} -- reduce the densification statistics over the ranks first "
-                               "(parallel.allreduce_densification_stats)")
+    _parallel.check_same_plan([kept, clones, splits, 1 if normals is None else 0], dev)
     if splits and normals is None:
         normals = torch.randn(2 * splits, 3, device=dev)
         # the children's positions are sampled: rank 0's samples are used everywhere instead of relying on lock-stepped per-rank RNG streams

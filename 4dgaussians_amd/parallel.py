@@ -28,6 +28,8 @@ def init_from_env(backend=None, timeout_s=None):
             raise RuntimeError(f"rank {rank} (LOCAL_RANK {local}) has no GPU of its own: {n_vis} device(s) visible; "
                                "the frame-parallel path runs one process per GPU and never shares a device")
         torch.cuda.set_device(device)
+        if world > 1:
+            pin_host_thread(device, local, world)
     if world > 1 and not dist.is_initialized():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -36,6 +38,91 @@ def init_from_env(backend=None, timeout_s=None):
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=t))
     return rank, world, device
+
+
+# ---- host placement: one rank = one host thread that enqueues ~40 launches per frame; on an 8-GPU node the ranks' threads are kept on the
+# cores of THEIR GPU's NUMA node (the enqueue path is ~1 ms of a 1.8 ms step: a thread migrating across sockets, or eight of them sharing a
+# few cores, shows up directly in the p90).  FDGS_NO_PIN=1 opts out.
+pinned_to = None          # what pin_host_thread did in this process (reported per rank by bench.py)
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/.../local_cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def cpus_for_rank(local_rank, world, allowed, numa_cpus=None):
+    """Host cores for rank `local_rank` of `world` on this node: the allowed cores of its GPU's NUMA node when known -- shared fairly when
+    several ranks' GPUs sit on the same node (the k-th of m ranks on a node gets the k-th m-th of its cores; `numa_cpus` = one core list per
+    rank) -- else an even slice of the allowed cores.  Never empty."""
+    allowed = sorted(allowed)
+    if numa_cpus is not None and numa_cpus[local_rank]:
+        mine = [c for c in numa_cpus[local_rank] if c in set(allowed)]
+        peers = [r for r in range(world) if numa_cpus[r] == numa_cpus[local_rank]]
+        if mine:
+            k, m = peers.index(local_rank), len(peers)
+            share = mine[k * len(mine) // m:(k + 1) * len(mine) // m]
+            return share or mine
+    n = len(allowed)
+    share = allowed[local_rank * n // world:(local_rank + 1) * n // world]
+    return share or allowed
+
+
+def _numa_cpus_of_gpu(index):
+    """Cores local to GPU `index` (sysfs local_cpulist of its PCI function), or None when the platform does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def pin_host_thread(device, local_rank, world):
+    """sched_setaffinity of this process to its share of the host cores (see above).  Returns the core list, or None when pinning is off
+    or unsupported."""
+    global pinned_to
+    if os.environ.get("FDGS_NO_PIN", "0") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+        numa = [_numa_cpus_of_gpu(r) for r in range(world)] if device.type == "cuda" else None
+        if numa is not None and any(x is None for x in numa):
+            numa = None
+        cpus = cpus_for_rank(local_rank, world, allowed, numa)
+        os.sched_setaffinity(0, cpus)
+        pinned_to = {"cpus": len(cpus), "first": cpus[0], "last": cpus[-1], "by": "numa_node_of_gpu" if numa is not None else "even_slice"}
+        return cpus
+    except Exception:
+        return None
+
+
+def check_same_plan(counts, device, what="densify"):
+    """Data-parallel replicas must restructure identically: all-reduce MIN and MAX of `counts` (ints) and raise on EVERY rank when they differ
+    -- before anything depends on the plan (a rank that went on alone would leave the others blocked in the next collective until the
+    process-group timeout).  No-op in a single-process job."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    mine = torch.tensor([int(c) for c in counts], device=device, dtype=torch.int64)
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"{what}: ranks disagree on the plan (kept, clones, splits, samples-drawn-here): min {lo.tolist()} max {hi.tolist()}, "
+                           f"this rank {mine.tolist()} -- reduce the densification statistics over the ranks first "
+                           "(parallel.allreduce_densification_stats)")
 
 
 def _free_port():
@@ -138,7 +225,7 @@ def gather_objects(obj):
 
 def device_identity(device):
     """What proves which physical GPU a rank ran on: UUID and PCI bus id where the runtime reports them, plus name and LOCAL_RANK."""
-    ident = {"device": str(device), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    ident = {"device": str(device), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(), "host_cpus_pinned": pinned_to}
     if device.type == "cuda":
         pr = torch.cuda.get_device_properties(device)
         ident["name"] = pr.name

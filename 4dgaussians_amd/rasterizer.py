@@ -48,15 +48,18 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # ---- pair-count bookkeeping of the binning stage -------------------------------------------------------------------------------------
 # The reference's rasterizer reads the number of (tile, Gaussian) pairs back to the host in the middle of every forward (to size its
-# binning buffer) and the host waits for it.  Here that read-back is taken off the frame's critical path: once a pair count has been seen
-# for an image size, the binning buffer is sized for a CAPACITY predicted from the largest count seen so far (x CAPACITY_SLACK) and the
-# whole forward is ONE non-blocking C call (fdgs_raster_fwd_capacity); the true count arrives in pinned host memory some time later and
-# is looked at when the NEXT frame starts: it feeds the predictor, and a count above the capacity (the farthest pairs of that frame were
-# dropped) raises a RuntimeWarning, is counted in `capacity_overflows`, and enlarges the capacity from then on.  The first frame of an image
-# size -- and every frame with BINNING = "exact" (FDGS_BINNING=exact) -- takes the reference's blocking path and is exact by construction.
+# binning buffer) and the host waits for it.  For TRAINING frames (a backward will follow) that read-back is taken off the critical path:
+# once a pair count has been seen for (image size, number of Gaussians), the binning buffer is sized for a CAPACITY predicted from the
+# largest count seen so far (x CAPACITY_SLACK) and the whole forward is ONE non-blocking C call (fdgs_raster_fwd_capacity); the true count
+# arrives in pinned host memory some time later and is looked at when the NEXT frame starts: it feeds the predictor, and a count above the
+# capacity raises a RuntimeWarning, is counted in `capacity_overflows`, and enlarges the capacity from then on.  An overflowing frame has
+# dropped its FARTHEST pairs -- forward and backward alike, so its gradient is the exact gradient of the image it returned -- which a
+# training loop absorbs like any other per-iteration noise; a frame whose image is the product (no backward expected: evaluation,
+# render.py, the metrics of training_report) ALWAYS takes the blocking exact path, as does the first frame of a (size, count) pair and
+# every frame with BINNING = "exact" (FDGS_BINNING=exact).  BINNING = "capacity" uses the capacity path for evaluation frames too.
 # State is per host thread (threading.local): one thread drives a stream, as include/fdgs.h requires.
 BINNING = os.environ.get("FDGS_BINNING", "auto")
-CAPACITY_SLACK = 1.3
+CAPACITY_SLACK = 1.5
 capacity_overflows = 0
 _SENTINEL = 0xFFFFFFFF
 _RING = 64
@@ -87,10 +90,12 @@ class PairCount:
 def _note_count(c):
     global capacity_overflows
     e = _seen.get(c.key)
-    if e is None or abs(c.P - e[1]) > 0.25 * max(e[1], 1):      # first frame of this image size, or another model: start over
+    if e is None:
+        if len(_seen) > 64:
+            _seen.clear()
         _seen[c.key] = [c.R, c.P]
     else:
-        e[0], e[1] = max(e[0], c.R), c.P
+        e[0] = max(e[0], c.R)
     if c.capacity is not None and c.R > c.capacity:
         capacity_overflows += 1
         warnings.warn(f"fdgs rasterizer: a frame listed {c.R} (tile, Gaussian) pairs but its binning buffer was sized for {c.capacity}: the "
@@ -163,9 +168,10 @@ class RasterState:
         return int(self.count.value())
 
 
-def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None):
+def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None, expect_backward=False):
     """Runs stages 1-4 of include/fdgs.h. Returns (color, radii, depth, state).  `out` = (color [3,H,W], radii [P] int32, depth [1,H,W])
-    buffers to write into (contiguous float32 / int32 on the device), e.g. slices of a batch tensor."""
+    buffers to write into (contiguous float32 / int32 on the device), e.g. slices of a batch tensor.  `expect_backward`: a training frame
+    (may take the non-blocking capacity path, see above); False = the image is the product: always the blocking exact path."""
     L = _lib.lib()
     dev = means3D.device
     if not _is_hip_device(dev):
@@ -207,13 +213,13 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     pending = tstate["pending"]
     if pending:           # counts of earlier frames that have arrived meanwhile: feed the predictor (never waits)
         tstate["pending"] = pending = [c for c in pending if c.poll() is None]
-    key = (dev.index, W, H)
+    key = (dev.index, W, H, P)          # (another model / a densified set: another key, i.e. one exact frame first)
     seen = _seen.get(key)
     cnt = PairCount()
     cnt.key, cnt.P, cnt.R, cnt.stream = key, P, None, None
     slot = ring[1] = (ring[1] + 1) % _RING
     cnt.addr = ring[0].data_ptr() + 4 * slot
-    if BINNING != "exact" and seen is not None and P > 0 and abs(P - seen[1]) <= 0.25 * max(seen[1], 1) and len(pending) < _RING - 2:
+    if BINNING != "exact" and (expect_backward or BINNING == "capacity") and seen is not None and P > 0 and len(pending) < _RING - 2:
         cap = (int(seen[0] * CAPACITY_SLACK) + 8192) // 4096 * 4096
         cnt.capacity = cap
         cnt.stream = _current_stream(dev)
@@ -265,9 +271,9 @@ def rasterize_backward(state, grad_color, grad_depth=None):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, grad_mode=True):
         color, radii, depth, state = rasterize_forward(raster_settings, means3D, sh, colors_precomp, opacities, scales,
-                                                       rotations, cov3Ds_precomp)
+                                                       rotations, cov3Ds_precomp, expect_backward=bool(grad_mode) and any(ctx.needs_input_grad))
         ctx.state = state
         ctx.had = (sh is not None and sh.numel() > 0, colors_precomp is not None and colors_precomp.numel() > 0,
                    scales is not None and scales.numel() > 0, cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0)
@@ -283,19 +289,20 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, grad_radii, grad_depth):
         if grad_color is None:
             if grad_depth is None:      # neither image reached the loss
-                return (None,) * 9
+                return (None,) * 10
             grad_color = torch.zeros(3, ctx.state.params.H, ctx.state.params.W, device=grad_depth.device)
         g = rasterize_backward(ctx.state, grad_color, grad_depth)
         had_sh, had_col, had_scale, had_cov = ctx.had
         op_shape, sh_shape = ctx.shapes
         return (g["means3D"], g["means2D"], g["shs"].reshape(sh_shape) if had_sh else None, g["colors"] if had_col else None,
                 g["opacities"].reshape(op_shape), g["scales"] if had_scale else None, g["rotations"] if had_scale else None,
-                g["cov3D"] if had_cov else None, None)
+                g["cov3D"] if had_cov else None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    # (grad mode is read HERE: inside autograd.Function.forward it is always off and needs_input_grad stays True under torch.no_grad())
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):

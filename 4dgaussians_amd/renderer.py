@@ -39,7 +39,8 @@ class _FusedRenderFunction(torch.autograd.Function):
     def forward(ctx, cfg, t_scalar, raster_settings, means2D, xyz, scales, rotations, opacity, sh_a, sh_b, aabb, *rest):
         st = _deformation.forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, None, aabb, rest,
                                        any(ctx.needs_input_grad))
-        color, radii, depth, rstate = _rasterizer.rasterize_forward(raster_settings, st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None)
+        color, radii, depth, rstate = _rasterizer.rasterize_forward(raster_settings, st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None,
+                                                                    expect_backward=bool(cfg.get("grad")) and any(ctx.needs_input_grad))
         ctx.st, ctx.rstate = st, rstate
         ctx.save_for_backward(st.o_sc, st.o_rot, st.o_op)       # (see _DeformFunction.forward: no reference cycle through ctx)
         st.o_xyz = st.o_sc = st.o_rot = st.o_op = st.o_sh = None
@@ -104,7 +105,7 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
         for v in range(nviews):
             st = _deformation.forward_impl(cfg, times[v], xyz, scales, rotations, opacity, sh_a, sh_b, None, aabb, rest, want)
             _, _, _, rstate = _rasterizer.rasterize_forward(settings_list[v], st.o_xyz, st.o_sh, None, st.o_op, st.o_sc, st.o_rot, None,
-                                                            out=(colors[v], radii_all[v], depths[v]))
+                                                            out=(colors[v], radii_all[v], depths[v]), expect_backward=bool(cfg.get("grad")) and want)
             st.o_xyz = st.o_sh = None
             states.append((st, rstate))
         ctx.states, ctx.nviews = states, nviews
@@ -198,7 +199,7 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, st
     planes, mlp = _deformation._collect(net)
     dn = net.deformation_net
     cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W, head_on=_deformation._head_on(dn.args),
-               activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()),
+               activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()), grad=torch.is_grad_enabled(),
                ordered=_deformation.spatial_order_hint(pc._xyz))
     colors, radii, depths = _FusedRenderViewsFunction.apply(cfg, times, settings, len(cams), *sinks, means3D, pc._scaling, pc._rotation,
                                                             pc._opacity, pc._features_dc, pc._features_rest, dn.grid.aabb, *planes, *mlp)
@@ -277,7 +278,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             dn = net.deformation_net
             cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W,
                        head_on=_deformation._head_on(dn.args), activate=True,
-                       save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()),
+                       save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()), grad=torch.is_grad_enabled(),
                        ordered=_deformation.spatial_order_hint(pc._xyz))
             rendered_image, radii, depth, vis = _FusedRenderFunction.apply(
                 cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,

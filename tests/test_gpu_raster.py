@@ -360,9 +360,10 @@ def test_blending_kernel_forms_agree(with_depth, monkeypatch):
 
 
 def test_capacity_mode_equals_the_blocking_exact_path(monkeypatch):
-    """rasterize_forward sizes the binning buffer from a predicted pair count once it has seen one for the image size and then runs the whole
-    forward as ONE non-blocking C call (fdgs_raster_fwd_capacity: the kernels read the true count on the device).  Same image, depth, radii
-    and per-pixel bookkeeping bit for bit, same sorted lists and ranges, same gradients as the blocking exact path."""
+    """For a training frame (`expect_backward`) rasterize_forward sizes the binning buffer from a predicted pair count once it has seen one
+    for (image size, Gaussian count) and runs the whole forward as ONE non-blocking C call (fdgs_raster_fwd_capacity: the kernels read the
+    true count on the device).  Same image, depth, radii and per-pixel bookkeeping bit for bit, same sorted lists and ranges, same gradients
+    as the blocking exact path -- which a frame without a backward (evaluation) always takes."""
     dev = torch.device("cuda:0")
     R = _mod().rasterizer
     sc = raster_scene(30000, 640, 480, seed=21, scale_boost=1.5)
@@ -372,11 +373,15 @@ def test_capacity_mode_equals_the_blocking_exact_path(monkeypatch):
     for mode in ("exact", "auto"):
         monkeypatch.setattr(R, "BINNING", mode)
         if mode == "auto":
-            assert (dev.index, 640, 480) in R._seen           # the exact frame above fed the predictor
+            assert (dev.index, 640, 480, 30000) in R._seen    # the exact frame above fed the predictor
         t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
         color, radii, depth, st = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
-                                                      t["rotations"], None)
+                                                      t["rotations"], None, expect_backward=True)
         if mode == "auto":
+            # ... and an evaluation frame (no backward expected) of the same scene stays on the exact path whatever the predictor knows
+            _, _, _, st_eval = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
+                                                   t["rotations"], None)
+            assert st_eval.count.capacity is None and st_eval.capacity == st_eval.num_rendered
             assert st.count.capacity is not None and st.capacity >= st.num_rendered > 0 and st.capacity % 4096 == 0
         else:
             assert st.count.capacity is None and st.capacity == st.num_rendered
@@ -406,14 +411,14 @@ def test_capacity_overflow_is_detected_and_the_capacity_grows(monkeypatch):
     monkeypatch.setattr(R, "BINNING", "auto")
     t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     args = (t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
-    key = (dev.index, 416, 304)
+    key = (dev.index, 416, 304, 20000)
     R._seen.pop(key, None)
-    color0, radii0, depth0, st0 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)          # first frame of this size: exact
+    color0, radii0, depth0, st0 = R.rasterize_forward(_settings(sc, dev, debug=False), *args, expect_backward=True)     # first frame of this (size, count): exact
     true_n = st0.num_rendered
     assert st0.count.capacity is None and true_n > 40000
     R._seen[key] = [true_n // 4, 20000]                                                                 # a predictor that is far too low
     before = R.capacity_overflows
-    color1, radii1, depth1, st1 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)
+    color1, radii1, depth1, st1 = R.rasterize_forward(_settings(sc, dev, debug=False), *args, expect_backward=True)
     assert st1.capacity < true_n
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
@@ -424,6 +429,6 @@ def test_capacity_overflow_is_detected_and_the_capacity_grows(monkeypatch):
     assert bool(torch.isfinite(color1).all()) and float((color1 - color0).abs().max()) > 0.0            # far pairs are missing, nothing else broke
     n_kept = int(_img(st1, 2, (((304 + 15) // 16) * ((416 + 15) // 16), 2), torch.int32, dev)[:, 1].max())
     assert n_kept <= st1.capacity
-    color2, radii2, depth2, st2 = R.rasterize_forward(_settings(sc, dev, debug=False), *args)          # the predictor has learnt
+    color2, radii2, depth2, st2 = R.rasterize_forward(_settings(sc, dev, debug=False), *args, expect_backward=True)     # the predictor has learnt
     assert st2.capacity >= true_n and st2.num_rendered == true_n
     assert torch.equal(color2, color0) and torch.equal(depth2, depth0)

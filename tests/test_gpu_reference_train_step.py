@@ -30,16 +30,18 @@ def test_reference_train_step_over_the_shims_matches_the_drop_ins():
     assert len(rep["events"]) == 4 and rep["N_final"][0] > rep["events"][0]["N_before"][0]          # the set actually grew
     assert any(ev["plan_B"][1] > 0 for ev in rep["events"]) and any(ev["plan_B"][2] > 0 for ev in rep["events"])   # clones AND splits happened
     for ev in rep["events"]:
-        if ev["N_before"][0] == ev["N_before"][1]:
-            # the statistics the densification decides on, accumulated over the 50 iterations since the last event
-            assert ev["accum_rel_l2"] < 2e-3 and ev["denom_mismatch_frac"] < 2e-3 and ev["max_radii2D_mismatch_frac"] < 5e-3, ev
+        assert ev["N_before"][0] == ev["N_before"][1]
+        # the statistics the densification decides on, accumulated over the 50 iterations since the segment started from identical state
+        # (measured on the first GPU run: 1.6e-4 / 0 / 0 after the first segment)
+        assert ev["accum_rel_l2"] < 2e-3 and ev["denom_mismatch_frac"] < 2e-3 and ev["max_radii2D_mismatch_frac"] < 1e-2 and ev["xyz_rel_l2"] < 1e-4, ev
         if ev["N_after"][0] != ev["N_after"][1]:
             # a different N is only acceptable for Gaussians that sat ON the threshold in the reference leg (|g / threshold - 1| < 1 %), all named
             assert 0 < ev.get("n_differently_selected", 0) <= 3 and all(abs(m) < 1e-2 for _, m in ev["differently_selected"]), ev
         else:
-            assert ev["table_equal"] and ev["xyz_rel_l2_after"] < 5e-3, ev
+            assert ev["table_equal"] and ev["xyz_rel_l2_after"] < 1e-3, ev
     first = rep["events"][0]
-    assert first["N_after"][0] == first["N_after"][1], first            # from identical state, the first densification agrees exactly
+    assert first["N_after"][0] == first["N_after"][1], first            # the first densification agrees exactly
+    assert sum(ev["N_after"][0] == ev["N_after"][1] for ev in rep["events"]) >= 3
     assert abs(mb - ma) < 0.05                                          # north_star: PSNR within 0.05 dB
     assert max(abs(a - b) for a, b in zip(rep["final_psnr_A"], rep["final_psnr_B"])) < 0.15
     assert np.abs(np.array(rep["psnr_A"][:40]) - np.array(rep["psnr_B"][:40])).max() < 0.01

@@ -365,3 +365,136 @@ def test_spawn_local_terminates_siblings_of_a_dead_rank():
     with pytest.raises(RuntimeError, match="exited non-zero"):
         par.spawn_local(2, _one_rank_dies_the_other_waits)
     assert time.monotonic() - t0 < 60.0        # (not the process-group timeout of minutes)
+
+
+# ---- eight ranks (the node the driver's --gpus 8 run uses), on gloo: every host-side piece of the N > 1 path at the world size it will meet ----
+def _dp_worker_n(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    r_, w_, dev = par.init_from_env(backend="gloo")
+    assert (r_, w_) == (rank, world) and par.ranks_seen(dev) == world
+    g = torch.Generator().manual_seed(7)
+    shapes = [(50, 3), (50, 16, 3), (7,), (4, 4), (1,)]
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    views = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(world)]     # same on every rank
+    for p, gr in zip(params, views[rank]):
+        p.grad = gr.clone()
+    if rank == 5:
+        params[2].grad = None                                                          # one rank's views never touched this tensor
+    params.append(torch.nn.Parameter(torch.zeros(3)))                                  # no grad anywhere: skipped everywhere
+    calls = par.allreduce_gradients(params, bucket_bytes=4096)
+    radii = torch.tensor([(rank * 3 + i * 5) % 11 for i in range(6)])
+    r, v, vg = par.allreduce_densification_stats(radii, radii > 4, torch.full((6, 3), float(rank + 1)))
+    acc = torch.tensor([float(rank), float(rank * rank), 10.0])
+    h = par.allreduce_loss_stats(acc, async_op=True)
+    h.wait()
+    # the densification plan check: agreeing ranks pass, one rank with another split count makes EVERY rank raise (nobody is left in a collective)
+    par.check_same_plan([100, 7, 3, 1], dev)
+    try:
+        par.check_same_plan([100, 7, 3 + (1 if rank == 6 else 0), 1], dev)
+        raised = False
+    except RuntimeError as e:
+        raised = "disagree" in str(e)
+    q.put((rank, calls, [p.grad.tolist() for p in params[:-1]], params[-1].grad is None, r.tolist(), v.tolist(), vg.tolist(), acc.tolist(), raised,
+           par.max_over_ranks(float(rank), dev), par.gather_floats(rank * 0.5, dev)))
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_rank_gradient_statistics_and_plan_check_on_gloo():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    shapes = [(50, 3), (50, 16, 3), (7,), (4, 4), (1,)]
+    views = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(world)]
+    want = [sum(views[r][i] for r in range(world) if not (r == 5 and i == 2)) for i in range(len(shapes))]
+    radii = [[(r * 3 + i * 5) % 11 for i in range(6)] for r in range(world)]
+    for rank, calls, grads, skipped, rr, vv, vg, acc, raised, mx, gf in res:
+        assert calls > 1 and skipped and raised
+        for got, w in zip(grads, want):
+            assert torch.allclose(torch.tensor(got), w, atol=1e-5)
+        assert rr == [max(radii[r][i] for r in range(world)) for i in range(6)]
+        assert vv == [any(radii[r][i] > 4 for r in range(world)) for i in range(6)]
+        assert torch.allclose(torch.tensor(vg), torch.full((6, 3), float(sum(range(1, world + 1)))))
+        assert acc == [float(sum(range(world))), float(sum(r * r for r in range(world))), 10.0 * world]
+        assert mx == float(world - 1) and gf == [0.5 * r for r in range(world)]
+
+
+def _bench_stub_rank_n(path, steps, warmup, repeats, world):
+    import importlib.util as ilu
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = ilu.spec_from_file_location("bench_stub_mod", os.path.join(root, "bench.py"))
+    bench = ilu.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import argparse
+    import contextlib
+    import io
+    args = argparse.Namespace(gpus=world, steps=steps, warmup=warmup, repeats=repeats)
+
+    def make_step(ctx):
+        def step(i, cam):
+            time.sleep(0.001 * (1 + (ctx["rank"] == world - 1)))       # the last rank is twice as slow
+        step.cpu_leg = lambda: ({"value": 0.3, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "stub"}, {"image_psnr_dB": 100.0, "grad_ok": True})
+        return step
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = bench.run(args, make_step=make_step)
+    with open(f"{path}.{os.environ['RANK']}", "w") as f:
+        f.write(repr((out, buf.getvalue())))
+
+
+def test_bench_rank_logic_at_world_size_eight(tmp_path):
+    """bench.run's skeleton (camera plan, barrier-bracketed regions reduced with MAX over ranks, rank-0 leg, per-rank report, one JSON line)
+    with EIGHT ranks on gloo -- the world size the driver's scaling run launches, which no test had reached."""
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    world, steps, warmup, repeats = 8, 4, 1, 2
+    path = str(tmp_path / "b8")
+    par.spawn_local(world, _bench_stub_rank_n, (path, steps, warmup, repeats, world))
+    res = [eval(open(f"{path}.{r}").read()) for r in range(world)]
+    import importlib.util as ilu
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = ilu.spec_from_file_location("bench_plan_mod8", os.path.join(root, "bench.py"))
+    bench = ilu.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = bench.rank_plan(160, steps, warmup, repeats, world)
+    for r, (out, printed) in enumerate(res):
+        assert out["cameras_rank_local"] == plan[r] and out["ranks_seen"] == world and out["n_gpus"] == world
+        assert len(out["per_rank_ms_per_step"]) == world
+        assert abs(out["value"] - world * steps / (out["ms_per_step"] * steps / 1e3)) < 1e-6      # whole-job frames/s
+        if r == 0:
+            line = json.loads(printed.strip())
+            rk = line["ranks"]
+            assert [x["rank"] for x in rk["per_rank"]] == list(range(world)) and rk["distinct_devices"] == world
+            assert line["cpu_baseline"]["value"] == 0.3 and line["parity"]["grad_ok"] is True
+        else:
+            assert printed.strip() == ""
+    assert len({res[r][0]["ms_per_step"] for r in range(world)}) == 1                           # everybody reports the MAX over ranks
+    every = sorted(c for r in range(world) for c in res[r][0]["cameras_rank_local"])
+    first = world * warmup
+    assert every == [c % 160 for c in range(first, first + world * steps * repeats)]              # every frame of the orbit exactly once
+
+
+def test_host_core_assignment_of_ranks():
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    assert par.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = range(192)
+    # no NUMA information: even slices, disjoint, covering
+    shares = [par.cpus_for_rank(r, 8, allowed) for r in range(8)]
+    assert all(len(s) == 24 for s in shares) and sorted(c for s in shares for c in s) == list(range(192))
+    # two NUMA nodes, four GPUs each: every rank inside its node, the four ranks of a node disjoint
+    numa = [list(range(0, 96))] * 4 + [list(range(96, 192))] * 4
+    shares = [par.cpus_for_rank(r, 8, allowed, numa) for r in range(8)]
+    assert all(set(s) <= set(numa[r]) and len(s) == 24 for r, s in enumerate(shares))
+    assert sorted(c for s in shares for c in s) == list(range(192))
+    # cores outside the process's allowed set are never chosen; a rank never ends up with nothing
+    assert par.cpus_for_rank(0, 8, [5], numa) == [5]
+    assert par.cpus_for_rank(7, 8, range(4)) != []

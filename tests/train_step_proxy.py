@@ -14,7 +14,11 @@ Two legs from identical state, both holding their Gaussians in the REFERENCE'S O
 The loop body is train.py:180-292 for batch size 1 in the fine stage (per-view render, L1 + plane regulariser, backward, max_radii2D update
 :259-261, statistics :262, densify :273, prune :277 [its N > 200 000 guard dropped so that the method runs], opacity reset :283, optimizer
 step :291), with the schedule shortened: densification every `interval` iterations, opacity reset once.  `torch.normal` (the split children,
-scene/gaussian_model.py:424) is fed the SAME pre-drawn samples in both legs.
+scene/gaussian_model.py:424) is fed the SAME pre-drawn samples in both legs.  After every densification event leg B continues from leg A's
+state (`resync_every_event`): an optimisation trajectory amplifies float rounding (Adam divides by sqrt(v) + 1e-15), so only a segment that
+STARTS from identical state can be compared to rounding; run with `resync_every_event=False` the two legs stayed on the same N through three
+densifications + a prune and differed by ONE Gaussian at the fourth -- three candidates within 0.5 % of the threshold
+(profiles/r05_reference_train_step_first_run.json).
 """
 import importlib
 import types
@@ -81,7 +85,8 @@ def _rel(a, b):
     return float((a - b).norm()) / d if d > 0 else float(a.norm())
 
 
-def run(iters=200, interval=50, n=3000, W=128, H=96, prune_at=100, reset_at=150, extent=3.0, device="cuda:0", grad_quantile=0.8, only_leg_a=False):
+def run(iters=200, interval=50, n=3000, W=128, H=96, prune_at=100, reset_at=120, extent=None, device="cuda:0", grad_quantile=0.8, only_leg_a=False,
+        resync_every_event=True):
     """Runs both legs in lock step.  Returns a report dict (see the test for what is asserted)."""
     from oracle import ref_modules
     fdgs = importlib.import_module("4dgaussians_amd")
@@ -90,6 +95,8 @@ def run(iters=200, interval=50, n=3000, W=128, H=96, prune_at=100, reset_at=150,
     student, cams, targets = fit_proxy.make_problem(n=n, W=W, H=H)
     hyper = student._deformation.args
     opt = train_opt(iters)
+    if extent is None:      # scene extent such that percent_dense * extent sits at the median splat size: clones AND splits happen
+        extent = float(torch.exp(student._scaling).max(1).values.median()) / opt.percent_dense
     A = _new_model(ns, student, dev, ns.deform_network(hyper))
     if only_leg_a:        # (CPU dry run of the reference side of this harness: tools only)
         return _run_leg_a_only(ns, A, opt, student, cams, targets, iters, interval, prune_at, reset_at, extent, grad_quantile, dev)
@@ -172,8 +179,11 @@ def run(iters=200, interval=50, n=3000, W=128, H=96, prune_at=100, reset_at=150,
             A.optimizer.zero_grad(set_to_none=True)
             B.optimizer.step()
             B.optimizer.zero_grad(set_to_none=True)
-            if it % interval == 0 and A._xyz.shape[0] != B._xyz.shape[0]:
-                _copy_state(fdgs, A, B)        # legs disagree on N (a Gaussian on the threshold): named above; continue from A's state
+            if it % interval == 0 and (resync_every_event or A._xyz.shape[0] != B._xyz.shape[0]):
+                # every segment starts from identical state (so that every event's statistics are comparable to rounding); without
+                # `resync_every_event` only when the legs disagree on N (a Gaussian on the threshold: named above)
+                rep["free_running_N_equal"] = rep.get("free_running_N_equal", True) and A._xyz.shape[0] == B._xyz.shape[0]
+                _copy_state(fdgs, A, B)
                 rep["resyncs"] += 1
     with torch.no_grad():
         rep["final_psnr_A"] = [float(ns.psnr(ns.render(c, A, pipe, bg, stage="fine")["render"][None], t[None]).mean()) for c, t in zip(cg, tg)]
