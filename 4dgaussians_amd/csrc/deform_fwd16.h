@@ -37,6 +37,17 @@
 #ifndef FDGS_D16_PD1
 #define FDGS_D16_PD1 2        // operand-request stages in flight per hidden-layer product (3 / 4 do not fit 256 registers without spills)
 #endif
+#ifndef FDGS_NT_SAVE
+#define FDGS_NT_SAVE 0        // 1: the saved activations (written once, read once by the backward ~1 ms later) leave with non-temporal stores
+#endif
+typedef float nt4f_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_saved16(float* dst, const float4& v) {
+#if FDGS_NT_SAVE
+    __builtin_nontemporal_store(nt4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4f_*>(dst));
+#else
+    *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
 __device__ __forceinline__ f32x4 mm16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
@@ -368,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     const size_t g_row = (size_t)g_raw;     // saved rows are indexed by the un-clamped Gaussian slot (< Npad)
     if (d.sv_feat && primary) {
 #pragma unroll
-        for (int u = 0; u < FU; u++) *reinterpret_cast<float4*>(d.sv_feat + g_row * d.F + 16 * u + 4 * q) = feat[u];
+        for (int u = 0; u < FU; u++) store_saved16(d.sv_feat + g_row * d.F + 16 * u + 4 * q, feat[u]);
     }
     f32x4 hid[WT16];
     T0.run(feat, hid);
@@ -386,7 +397,7 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
     auto drain_piece = [&](int j) {
         if (pending_dst && j < NPIECE) {
             const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4);
-            reinterpret_cast<float4*>(pending_dst)[e4] = *reinterpret_cast<const float4*>(my_tile + row * LDW + 4 * c4);
+            store_saved16(pending_dst + 4 * (size_t)e4, *reinterpret_cast<const float4*>(my_tile + row * LDW + 4 * c4));
         }
     };
     if (d.sv_rh && primary) {
