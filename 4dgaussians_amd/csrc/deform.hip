@@ -1098,7 +1098,12 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         // transposed product of the current one -- the kernel is otherwise HBM-latency bound on these 16-KB tiles
         // (sixteen named registers quadruples, not an array: an array carried across the head loop is "promoted" to LDS by
         // the compiler's alloca pass instead of being scalarised)
+#if defined(FDGS_NT_LOAD) && FDGS_NT_LOAD      // (development variant: the saved rows are read once)
+#define FDGS_TV_LOAD(j) if (j < WT * 4) { typedef float v4nt_ __attribute__((ext_vector_type(4))); \
+        const v4nt_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4nt_*>(tsrc + (j * 64 + lane))); tv##j = make_float4(t_.x, t_.y, t_.z, t_.w); }
+#else
 #define FDGS_TV_LOAD(j) if (j < WT * 4) tv##j = tsrc[j * 64 + lane];
+#endif
 #define FDGS_TV_STORE(j) if (j < WT * 4) { const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4); \
                                           *reinterpret_cast<float4*>(lds + row * STRIDE + 4 * c4) = tv##j; }
         if constexpr (SAVED) {
