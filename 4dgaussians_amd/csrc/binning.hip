@@ -563,6 +563,9 @@ extern "C" int fdgs_img_field(void* img, int W, int H, int which, void** ptr) {
     if (which == 0) *ptr = at<char>(img, il.final_T);
     else if (which == 1) *ptr = at<char>(img, il.n_contrib);
     else if (which == 2) *ptr = at<char>(img, il.ranges);
+    else if (which == 3) *ptr = at<char>(img, il.todo);
+    else if (which == 4) *ptr = at<char>(img, il.order_f);
+    else if (which == 5) *ptr = at<char>(img, il.order_b);
     else return fail(FDGS_E_INVALID, "%s", "unknown img field");
     return FDGS_OK;
 }

@@ -62,6 +62,7 @@ struct Tuning {
     int d4_rows_kb;  // FDGS_D4_ROWS_KB  -1 = the time rows get all the LDS that is left; >= 0 caps it (tests: rows that do not fit)
     int tile_cull;   // FDGS_TILE_CULL   1 = exact tile culling, 0 = the reference's rectangle lists
     int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: 4 (default) | 2 | 0 = the 256-thread form
+    int tile_order;  // FDGS_TILE_ORDER  1 = the blending kernels take their tiles heaviest-first (per XCD), 0 = in image order
 };
 extern Tuning g_tune;
 
@@ -155,9 +156,13 @@ inline BinLayout bin_layout(uint32_t R) {
     b.bytes = o;
     return b;
 }
+// tile rows per XCD group of the blending kernels' block -> tile map (render.hip: unit_of_block; sweep 0 / 1 / 2 / 4 in
+// profiles/r03f_bench_cfg4_xcd*.json) and the largest per-XCD tile count the heaviest-first ordering sorts in LDS
+constexpr int XCD_ROWS = 2;
+constexpr int TILE_ORDER_MAX = 8192;
 struct ImgLayout {
-    size_t final_T, n_contrib, ranges, bytes;
-    int gx, gy;
+    size_t final_T, n_contrib, ranges, todo, order_f, order_b, bytes;
+    int gx, gy, per_xcd;       // per_xcd = tiles (incl. padding) each of the 8 XCDs owns in the block -> tile map
 };
 inline ImgLayout img_layout(int W, int H) {
     ImgLayout m{};
@@ -167,6 +172,11 @@ inline ImgLayout img_layout(int W, int H) {
     m.final_T = take((size_t)W * H * 4);
     m.n_contrib = take((size_t)W * H * 4);
     m.ranges = take((size_t)m.gx * m.gy * 8);
+    const int groups = (m.gy + XCD_ROWS - 1) / XCD_ROWS;
+    m.per_xcd = ((groups + 7) / 8) * XCD_ROWS * m.gx;
+    m.todo = take((size_t)m.gx * m.gy * 4);            // per tile: entries the backward walks (max n_contrib), written by the forward
+    m.order_f = take((size_t)8 * m.per_xcd * 4);       // heaviest-first tile order per XCD: forward (by list length) ...
+    m.order_b = take((size_t)8 * m.per_xcd * 4);       // ... and backward (by `todo`)
     m.bytes = o;
     return m;
 }

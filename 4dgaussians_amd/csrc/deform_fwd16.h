@@ -38,8 +38,8 @@
 #define FDGS_D16_PD1 2        // operand-request stages in flight per hidden-layer product (3 / 4 do not fit 256 registers without spills)
 #endif
 #ifndef FDGS_NT_SAVE
-#define FDGS_NT_SAVE 0        // 1: the saved activations (written once, read once by the backward ~1 ms later) leave with non-temporal stores
-#endif
+#define FDGS_NT_SAVE 1        // the saved activations (written once, read once by the backward ~1 ms later) leave with non-temporal stores:
+#endif                         // +0.2 .. 0.6 % frames/s in the frame, cube and shell scene (profiles/r05_variants_ab_nt_ppl_form.txt; 0 = plain stores)
 typedef float nt4f_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_saved16(float* dst, const float4& v) {
 #if FDGS_NT_SAVE

@@ -33,6 +33,66 @@ __host__ __device__ __forceinline__ int unit_grid(int gx, int gy, int parts, int
     const int groups = (gy + bh - 1) / bh;
     return 8 * ((groups + 7) / 8) * bh * gx * parts;
 }
+// Heaviest-first dispatch (round 5).  A blending kernel is ONE wave (backward) or one workgroup (forward) per tile, the tiles' list
+// lengths differ by 5x between the rim and the centre of the image, and with 5 440 tiles on 1 024 SIMDs x 4 wave slots nearly every
+// tile is resident from the start: nothing balances the load, a SIMD that drew four centre tiles finishes long after one that drew
+// four rim tiles (a dispatch simulation on the bench frame's per-tile work puts the backward at 0.62 of perfect balance in image order
+// and at 0.82 heaviest-first; tools/tile_balance_sim.py).  `order` (tile_order_kernel) lists each XCD's tiles by descending work: block b
+// still runs on XCD b % 8 and still only takes tiles of that XCD's row groups (their Gaussians stay in its L2), but the heavy ones are
+// dispatched first and the light ones fill in behind them.  order == nullptr: image order.
+__device__ __forceinline__ int unit_lookup(const uint32_t* __restrict__ order, int per_xcd, int b, int gx, int gy, int parts, int bh) {
+    if (!order) return unit_of_block(b, gx, gy, parts, bh);
+    const int xcd = b & 7, idx = b >> 3;
+    const uint32_t t = order[xcd * per_xcd + idx / parts];
+    return t == 0xFFFFFFFFu ? -1 : (int)t * parts + idx % parts;
+}
+// One 1024-thread workgroup per XCD: counting sort of the XCD's tiles by descending key (256 levels of the XCD's largest key; LPT needs
+// no finer order), key = list length (mode 0, forward) or the forward's per-tile `todo` (mode 1, backward).  Padding slots of the map
+// (rows below the image) and tiles with key 0 go last.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int mode, int gx, int gy, int bh, int per_xcd, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ todo, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[256], base[256], smax;
+    const int x = blockIdx.x, t = threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    if (t == 0) smax = 0;
+    __syncthreads();
+    constexpr int PER = TILE_ORDER_MAX / 1024;
+    int tile[PER];
+    uint32_t key[PER];
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int idx = t + 1024 * i;
+        tile[i] = idx < per_xcd ? unit_of_block(idx * 8 + x, gx, gy, 1, bh) : -2;      // -1: padding slot of the map, -2: beyond the map
+        key[i] = 0;
+        if (tile[i] >= 0) key[i] = mode == 0 ? ranges[tile[i]].y - ranges[tile[i]].x : todo[tile[i]];
+        m = key[i] > m ? key[i] : m;
+    }
+    if (m) atomicMax(&smax, m);
+    __syncthreads();
+    const uint32_t mx = smax > 0 ? smax : 1u;
+    uint32_t bucket[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        bucket[i] = 255u - (uint32_t)(((unsigned long long)key[i] * 255ull) / mx);
+        if (tile[i] == -1) bucket[i] = 255u;
+        if (tile[i] != -2) atomicAdd(&hist[bucket[i]], 1u);
+    }
+    __syncthreads();
+    if (t < 64) {       // exclusive scan of the 256 counts by one wave: four per lane
+        const uint32_t c0 = hist[4 * t], c1 = hist[4 * t + 1], c2 = hist[4 * t + 2], c3 = hist[4 * t + 3];
+        uint32_t inc = c0 + c1 + c2 + c3;
+        const uint32_t tot = inc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if (t >= o) inc += u; }
+        const uint32_t ex = inc - tot;
+        base[4 * t] = ex; base[4 * t + 1] = ex + c0; base[4 * t + 2] = ex + c0 + c1; base[4 * t + 3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (tile[i] != -2) order[(size_t)x * per_xcd + atomicAdd(&base[bucket[i]], 1u)] = tile[i] >= 0 ? (uint32_t)tile[i] : 0xFFFFFFFFu;
+}
 
 // The exponent of a blended Gaussian, written so that EVERY kernel that evaluates it rounds it the same way (the forward decides
 // alpha >= 1/255 and T < 1e-4 from it, the backward has to take the same decisions): -0.5 * (dx*(dx*cxx) + dy*(dy*cyy)) - dy*(dx*cxy),
@@ -63,6 +123,8 @@ __device__ __forceinline__ v2f_ blend_power2(float u1, float cx, float cyy, v2f_
 
 struct RenderArgs {
     int W, H, gx, gy, bh;
+    const uint32_t* order; int per_xcd;      // heaviest-first tile order (nullptr: image order)
+    uint32_t* tile_todo;                     // out, per tile: max n_contrib = the entries the backward will walk
     const uint2* ranges; const uint32_t* pair_gid;
     const float4 *recA, *recB, *recC;
     const float* bg;
@@ -71,9 +133,10 @@ struct RenderArgs {
 };
 
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
-    const int tile = unit_of_block(blockIdx.x, a.gx, a.gy, 1, a.bh);
+    const int tile = unit_lookup(a.order, a.per_xcd, blockIdx.x, a.gx, a.gy, 1, a.bh);
     if (tile < 0) return;
     __shared__ float4 sA[256], sB[256], sC[256];
+    __shared__ uint32_t sTodo[4];
     const int t = threadIdx.x;
     const int x = (tile % a.gx) * TILE + (t & 15), y = (tile / a.gx) * TILE + (t >> 4);
     const bool inside = x < a.W && y < a.H;
@@ -118,6 +181,18 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
         a.out_color[hw + pix] = C1 + T * a.bg[1];
         a.out_color[2 * hw + pix] = C2 + T * a.bg[2];
         a.out_depth[pix] = Dp;
+    }
+    {   // the tile's walk length for the backward (its work: the key of the backward's heaviest-first order)
+        uint32_t m = inside ? last : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+        __syncthreads();            // (the staging loop above may have been left at different points: sTodo is only touched here)
+        if ((t & 63) == 0) sTodo[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) {
+            uint32_t q = sTodo[0]; q = sTodo[1] > q ? sTodo[1] : q; q = sTodo[2] > q ? sTodo[2] : q; q = sTodo[3] > q ? sTodo[3] : q;
+            a.tile_todo[tile] = q;
+        }
     }
 }
 
@@ -179,6 +254,7 @@ __device__ __forceinline__ float wave_reduce_scatter10(float a0, float a1, float
 
 struct RenderBwdArgs {
     int W, H, gx, gy, bh;
+    const uint32_t* order; int per_xcd;      // heaviest-first tile order (nullptr: image order)
     const uint2* ranges; const uint32_t* pair_gid;
     const float4 *recA, *recB, *recC;
     const float* bg;
@@ -198,7 +274,7 @@ struct RenderBwdArgs {
 // profiles/r01_lds_atomic_microbench.txt, and rocprofv3 showed the waves waiting 39 % of their cycles.)
 template <bool DEPTH, int ROUND>
 __global__ void __launch_bounds__(256) render_bwd_kernel(RenderBwdArgs a) {
-    const int tile = unit_of_block(blockIdx.x, a.gx, a.gy, 1, a.bh);
+    const int tile = unit_lookup(a.order, a.per_xcd, blockIdx.x, a.gx, a.gy, 1, a.bh);
     if (tile < 0) return;
     constexpr int NV = DEPTH ? 10 : 9;
     __shared__ float4 sA[ROUND], sB[ROUND], sC[ROUND];
@@ -355,7 +431,7 @@ template <bool DEPTH, int NP>
 __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
     constexpr int PPL = 2 * NP;
     constexpr int PARTS = 4 / PPL;
-    const int unit = unit_of_block(blockIdx.x, a.gx, a.gy, PARTS, a.bh);
+    const int unit = unit_lookup(a.order, a.per_xcd, blockIdx.x, a.gx, a.gy, PARTS, a.bh);
     if (unit < 0) return;
     const int tile = unit / PARTS, part = unit - tile * PARTS;
     __shared__ float4 sA[64], sB[64], sC[64];
@@ -491,8 +567,17 @@ __global__ void __launch_bounds__(64) render_bwd_strip_kernel(RenderBwdArgs a) {
 
 int validate_raster_params(const fdgs_raster_params* p);
 
-// tile rows per XCD group (unit_of_block): 2 (sweep 0 / 1 / 2 / 4 in profiles/r03f_bench_cfg4_xcd*.json; 0 was one contiguous band per XCD)
-static int tile_rows_per_xcd_group(int) { return 2; }
+// tile rows per XCD group (unit_of_block): common.h XCD_ROWS (0 was one contiguous band per XCD)
+static int tile_rows_per_xcd_group(int) { return XCD_ROWS; }
+// launches tile_order_kernel when the knob is on and an XCD's tiles fit its LDS sort; returns the order to hand to the kernel (or nullptr)
+static const uint32_t* make_tile_order(hipStream_t stream, int mode, const ImgLayout& il, const void* img, void* img_w) {
+    if (!g_tune.tile_order || il.per_xcd > TILE_ORDER_MAX || il.per_xcd < 1) return nullptr;
+    uint32_t* order = at<uint32_t>(img_w, mode == 0 ? il.order_f : il.order_b);
+    FDGS_TIMED("tile_order", stream);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, mode, il.gx, il.gy, XCD_ROWS, il.per_xcd, at<uint2>(img, il.ranges),
+                       at<uint32_t>(img, il.todo), order);
+    return order;
+}
 
 }  // namespace fdgs
 
@@ -515,6 +600,8 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     a.recA = at<float4>(geom, gl.recA); a.recB = at<float4>(geom, gl.recB); a.recC = at<float4>(geom, gl.recC);
     a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
     a.out_color = out_color; a.out_depth = out_depth;
+    a.tile_todo = at<uint32_t>(img, il.todo); a.per_xcd = il.per_xcd;
+    a.order = R > 0 ? make_tile_order(stream, 0, il, img, img) : nullptr;
     {
         FDGS_TIMED("render_fwd", stream);
         hipLaunchKernelGGL(render_fwd_kernel, dim3(unit_grid(a.gx, a.gy, 1, a.bh)), dim3(256), 0, stream, a);
@@ -556,6 +643,10 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
         a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
         a.dL_dcolor = g->dL_dcolor; a.dL_ddepth = g->dL_ddepth;
         a.gacc = g->scratch_acc;
+        // (the order lists live in `img`, the forward's state, which this call otherwise only reads: the slice written here is scratch of the
+        // backward that belongs to this frame -- one backward per forward state at a time, as for every other buffer of the state)
+        a.per_xcd = il.per_xcd;
+        a.order = make_tile_order(stream, 1, il, img, const_cast<void*>(img));
         {
             FDGS_TIMED("render_bwd", stream);
             // (256-thread form: 128 entries staged per round keeps six workgroups per CU at 25 KB of LDS each)

@@ -43,10 +43,11 @@ int fdgs_abi_version(void);
  * roofline measurement).  fdgs_timing_report synchronises the device and writes "kernel_name count total_ms" lines. */
 int fdgs_timing_enable(int on);
 int fdgs_timing_report(char* buf, size_t buflen, int reset);
-/* Development / test knobs (ABI 4).  The library holds ONE table of eight integer knobs; it is filled from the environment variables
+/* Development / test knobs (ABI 4).  The library holds ONE table of nine integer knobs; it is filled from the environment variables
  * FDGS_<NAME> once, when the library is loaded, and afterwards changes only through fdgs_tuning_set -- no entry point reads the
  * environment.  Knobs select between equivalent kernel forms or launch shapes (same results up to summation order), never semantics:
- *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (4 | 2 | 0).
+ *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (4 | 2 | 0),
+ *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order).
  * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
  * set knobs between frames.  fdgs_tuning_reset restores the load-time values.  See INTEGRATION.md ("Knobs"). */
 int fdgs_tuning_set(const char* name, int value);
@@ -181,7 +182,9 @@ int fdgs_mark_visible(void* stream, int P, const float* means3D, const float* vi
 int fdgs_geom_field(void* geom, int P, int which, void** ptr);
 /* 0 sorted pair Gaussian ids u32[R]; 1 sorted pair tile ids u32[R]. */
 int fdgs_binning_field(void* binning, uint32_t num_rendered, int W, int H, int which, void** ptr);
-/* 0 final_T f32[H*W]; 1 n_contrib u32[H*W]; 2 ranges u32[ntiles,2]. */
+/* 0 final_T f32[H*W]; 1 n_contrib u32[H*W]; 2 ranges u32[ntiles,2]; 3 per-tile walk length of the backward u32[ntiles] (max n_contrib);
+ * 4 / 5 heaviest-first tile order of the forward / backward, u32[8][per_xcd] with per_xcd = ceil(ceil(gy / 2) / 8) * 2 * gx (0xFFFFFFFF =
+ * padding slot; written only while the tuning knob tile_order is on and per_xcd <= 8192). */
 int fdgs_img_field(void* img, int W, int H, int which, void** ptr);
 
 /* ------------------------------------------------------------------------------------------------------------

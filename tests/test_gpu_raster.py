@@ -432,3 +432,57 @@ def test_capacity_overflow_is_detected_and_the_capacity_grows(monkeypatch):
     color2, radii2, depth2, st2 = R.rasterize_forward(_settings(sc, dev, debug=False), *args, expect_backward=True)     # the predictor has learnt
     assert st2.capacity >= true_n and st2.num_rendered == true_n
     assert torch.equal(color2, color0) and torch.equal(depth2, depth0)
+
+
+@pytest.mark.parametrize("ppl", [4, 2, 0])
+def test_heaviest_first_tile_order_changes_nothing_but_the_dispatch_order(ppl):
+    """The blending kernels take their tiles heaviest-first per XCD (tuning knob tile_order, csrc/render.hip: tile_order_kernel): the order
+    lists are permutations of each XCD's tiles of the image-order map, sorted by descending work to the 256 levels of the counting sort
+    (forward: list length; backward: the walk length the forward left per tile), and forward outputs are bit-identical with and without it;
+    gradients agree to the association of the atomics."""
+    import ctypes
+    dev = torch.device("cuda:0")
+    R = _mod().rasterizer
+    L = _mod()._lib.lib()
+    Wd, Ht = 420, 300
+    sc = raster_scene(24000, Wd, Ht, seed=31, scale_boost=1.6)
+    rng = np.random.default_rng(7)
+    wc = torch.tensor(rng.standard_normal((3, Ht, Wd)).astype(np.float32), device=dev)
+    set_knob("rbwd_ppl", ppl)
+    outs = {}
+    for on in (1, 0):
+        set_knob("tile_order", on)
+        t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        color, radii, depth, st = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
+                                                      t["rotations"], None)
+        g = R.rasterize_backward(st, wc)
+        torch.cuda.synchronize()
+        gx, gy = (Wd + 15) // 16, (Ht + 15) // 16
+        per_xcd = -(-(-(-gy // 2)) // 8) * 2 * gx
+        outs[on] = dict(color=color.clone(), depth=depth.clone(), ncontrib=_img(st, 1, (Ht, Wd), torch.int32, dev), grads={k: v.clone() for k, v in g.items() if v is not None},
+                        ranges=_img(st, 2, (gx * gy, 2), torch.int32, dev), todo=_img(st, 3, (gx * gy,), torch.int32, dev),
+                        order_f=_img(st, 4, (8, per_xcd), torch.int32, dev).view(np.uint32), order_b=_img(st, 5, (8, per_xcd), torch.int32, dev).view(np.uint32))
+    a, b = outs[1], outs[0]
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"]) and np.array_equal(a["ncontrib"], b["ncontrib"])
+    for k in a["grads"]:
+        assert rel_l2(a["grads"][k].cpu().numpy(), b["grads"][k].cpu().numpy()) < 5e-6, k
+    # the forward's per-tile walk length = max n_contrib over the tile's pixels
+    pad = np.zeros((gy * 16, gx * 16), np.int64)
+    pad[:Ht, :Wd] = a["ncontrib"]
+    assert np.array_equal(a["todo"].astype(np.int64), pad.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1))
+    # the order lists: per XCD a permutation of its tiles, non-increasing in the sort's 256 levels
+    length = (a["ranges"][:, 1].astype(np.int64) - a["ranges"][:, 0].astype(np.int64))
+    for name, key in (("order_f", length), ("order_b", a["todo"].astype(np.int64))):
+        seen = []
+        for x in range(8):
+            row = a[name][x]
+            tiles = row[row != 0xFFFFFFFF].astype(np.int64)
+            # image-order map of this XCD: groups of two tile rows, group G belongs to XCD G % 8
+            mine = [ty * gx + tx for ty in range(gy) if (ty // 2) % 8 == x for tx in range(gx)]
+            assert sorted(tiles.tolist()) == sorted(mine), (name, x)
+            assert (row == 0xFFFFFFFF).sum() == per_xcd - len(mine) and not (row[:len(mine)] == 0xFFFFFFFF).any() or key[tiles].min() == 0
+            mx = max(int(key[tiles].max()), 1) if len(tiles) else 1
+            level = 255 - (key[tiles] * 255) // mx
+            assert np.all(np.diff(level) >= 0), (name, x)
+            seen += tiles.tolist()
+        assert sorted(seen) == list(range(gx * gy))
