@@ -70,11 +70,12 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int mode, int gx, int 
     }
     if (m) atomicMax(&smax, m);
     __syncthreads();
-    const uint32_t mx = smax > 0 ? smax : 1u;
+    const float scale = 255.0f / (float)(smax > 0 ? smax : 1u);
     uint32_t bucket[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        bucket[i] = 255u - (uint32_t)(((unsigned long long)key[i] * 255ull) / mx);
+        const uint32_t lvl = (uint32_t)((float)key[i] * scale);         // (monotonic in the key: all the order needs)
+        bucket[i] = 255u - (lvl < 255u ? lvl : 255u);
         if (tile[i] == -1) bucket[i] = 255u;
         if (tile[i] != -2) atomicAdd(&hist[bucket[i]], 1u);
     }
