@@ -393,10 +393,10 @@ def run(args, make_step=None):
             # the same self-check as the headline frame, on THIS scene (one oracle frame on the host, outside every timed region)
             def other_leg():
                 cam_p = cams[args.warmup % len(cams)]
-                _, ref_s = cpu_baseline(fdgs, syn, pc_s, cam_p, target, dcfg, 1)
+                _, ref_s = cpu_baseline(fdgs, syn, pc_s, cam_p, target, dcfg, 1, deformed=hip_deformed(fdgs, pc_s, cam_p))
                 prm_s = [p_ for p_ in pc_s.parameters() if p_.requires_grad]
                 full = parity_vs_oracle(fdgs, pc_s, cam_p, pipe, bg, prm_s, ref_s)
-                keep = ("image_psnr_dB", "n_pixels_over_1e-4", "n_pixels", "radii_mismatch_frac", "grad_rel_l2_vs_float64_oracle",
+                keep = ("deformation_max_abs_vs_oracle", "image_psnr_dB", "n_pixels_over_1e-4", "n_pixels", "radii_mismatch_frac", "grad_rel_l2_vs_float64_oracle",
                         "grad_rel_l2_vs_float64_oracle_kink_rows_attributed", "kink_rows", "n_kink_rows", "max_kink_rows", "unexplained_rows",
                         "n_unexplained_rows", "attribution_windows", "grad_ok", "grad_failures", "viewspace_rel_l2")
                 return {k: full[k] for k in keep}
@@ -488,7 +488,7 @@ def run(args, make_step=None):
     if not args.no_cpu_baseline:
         def cpu_leg():
             cam_p = cams[args.warmup % len(cams)]
-            cpu_, ref = cpu_baseline(fdgs, syn, pc, cam_p, target, dcfg, args.cpu_frames)
+            cpu_, ref = cpu_baseline(fdgs, syn, pc, cam_p, target, dcfg, args.cpu_frames, deformed=hip_deformed(fdgs, pc, cam_p))
             return cpu_, parity_vs_oracle(fdgs, pc, cam_p, pipe, bg, params, ref)
         leg = rank0_leg(par, rank, cpu_leg)        # rank 0, whatever the world size (the other ranks wait)
         if leg is not None:
@@ -607,11 +607,14 @@ def pmc_traffic(kernel, workload, lib_sha):
             if reasons else "no PMC artefact under profiles/"}
 
 
-def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
+def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames, deformed=None):
     """The same frame on the host cores: oracle deformation (torch CPU) -> oracle rasterizer (C, OpenMP), fwd + bwd.
     kind = "port": the rasterizer restatement is ours (the reference has no CPU rasterizer); the deformation oracle is
     pinned to the reference's modules (tests/test_oracle_deform.py).  Bounded sample: `frames` full frame(s) of the bench
-    workload on min(cores, 64) threads (more threads only add scheduling overhead to these memory-bound loops)."""
+    workload on min(cores, 64) threads (more threads only add scheduling overhead to these memory-bound loops).
+    `deformed` = the HIP deformation's outputs for this frame (CPU tensors): the PARITY reference (second return value) is then computed in
+    one extra, untimed pass in which the C rasterizer blends THOSE Gaussians (oracle/chain.py explains why parity is factored into
+    deformation-vs-oracle and rasterizer-vs-oracle-on-the-same-inputs); the timed sample is always the pure oracle chain."""
     import numpy as np
     from oracle import deform_oracle as DO
     from oracle import raster_oracle as RO
@@ -629,15 +632,20 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
     n = leaves["_xyz"].shape[0]
     stage = {"deform_fwd": 0.0, "raster_fwd": 0.0, "raster_bwd": 0.0, "deform_bwd": 0.0}
     ref = None
+    passes = [None] * frames + ([deformed] if deformed is not None else [])      # the last pass (untimed) builds the factored parity reference
     t0 = time.perf_counter()
-    for fi in range(frames):
+    dt = None
+    for fi, given in enumerate(passes):
+        if fi == frames:
+            dt = time.perf_counter() - t0
         ta = time.perf_counter()
         shs = torch.cat([leaves["_features_dc"], leaves["_features_rest"]], 1)
         outs = DO.deform_forward(sd, flags, leaves["_xyz"], leaves["_scaling"], leaves["_rotation"], leaves["_opacity"], shs,
                                  torch.full((n, 1), cam.time), activate=True)
         tb = time.perf_counter()
-        f = lambda x: np.ascontiguousarray(x.detach().numpy())
-        o = RO.RasterOracle(means3D=f(outs[0]), scales=f(outs[1]), rotations=f(outs[2]), opacities=f(outs[3]), shs=f(outs[4]),
+        f = lambda x: np.ascontiguousarray(x.detach().cpu().float().numpy())
+        rin = outs if given is None else [g_.reshape(o_.shape) for g_, o_ in zip(given, outs)]
+        o = RO.RasterOracle(means3D=f(rin[0]), scales=f(rin[1]), rotations=f(rin[2]), opacities=f(rin[3]), shs=f(rin[4]),
                             viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
                             bg=np.zeros(3, np.float32), image_height=cam.image_height, image_width=cam.image_width,
                             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
@@ -650,14 +658,17 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
         wanted = list(leaves.values()) + [v for v in sd.values() if v.requires_grad]
         gref = torch.autograd.grad(list(outs), wanted, grad_outputs=gouts, allow_unused=True)
         te = time.perf_counter()
-        if fi == 0:   # the oracle's image, depth and every gradient of this frame: the checker of parity_vs_oracle()
+        if fi == len(passes) - 1:   # the oracle's image, depth and every gradient of this frame: the checker of parity_vs_oracle()
             names = list(leaves.keys()) + ["_deformation." + k for k, v in sd.items() if v.requires_grad]
             ref = dict(color=o.color.copy(), depth=o.depth.copy(), dc=dc, means2D=g["means2D"].copy(), radii=o.radii.copy(),
-                       grads={k: (None if v is None else v.numpy()) for k, v in zip(names, gref)}, gouts=[x.clone() for x in gouts])
+                       grads={k: (None if v is None else v.numpy()) for k, v in zip(names, gref)}, gouts=[x.clone() for x in gouts],
+                       deformed_oracle=[t.detach().clone() for t in outs], factored=given is not None)
         o.close()
-        for k_, v_ in zip(stage, (tb - ta, tc - tb, td - tc, te - td)):
-            stage[k_] += v_
-    dt = time.perf_counter() - t0
+        if fi < frames:
+            for k_, v_ in zip(stage, (tb - ta, tc - tb, td - tc, te - td)):
+                stage[k_] += v_
+    if dt is None:
+        dt = time.perf_counter() - t0
     # outside the timed sample: the float64 re-evaluation of the deformation backward of frame 0 (live rows only) -- the gradient
     # reference that is not itself at the mercy of one ReLU kink (oracle/deform_oracle.py: backward_float64)
     ref["grads64"] = DO.backward_float64(sd, flags, leaves, cam.time, ref["gouts"])
@@ -666,6 +677,14 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames):
             "sample": f"{frames} full frame(s) of the same workload (fwd+bwd), {dt:.1f} s wall on {threads} threads of {cores} host cores; "
                       "deformation = oracle pinned to the reference modules (torch CPU), rasterizer = our C restatement (OpenMP)",
             "stage_seconds": {k_: round(v_, 3) for k_, v_ in stage.items()}}, ref)
+
+
+def hip_deformed(fdgs, pc, cam):
+    """The HIP deformation's outputs for this frame (CPU tensors): what the factored parity reference lets the C rasterizer blend."""
+    with torch.no_grad():
+        out = fdgs.deformation.deform(pc._deformation, pc._xyz, pc._scaling, pc._rotation, pc._opacity, shs_dc=pc._features_dc,
+                                      shs_rest=pc._features_rest, time=cam.time, activate=True)
+    return [t.cpu() for t in out]
 
 
 def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
@@ -707,7 +726,16 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
     worst_tensor = max(((k, rel(impl[k], v)) for k, v in ref["grads64"].items()
                         if v is not None and float(np.abs(v).max()) > 0), key=lambda kv: kv[1])
     radii = res["radii"].cpu().numpy()
+    hd = hip_deformed(fdgs, pc, cam)
+    n_ = hd[0].shape[0]
+    stage_a = {k: float(f"{float((a.reshape(n_, -1) - b.reshape(n_, -1)).abs().max()):.3e}")
+               for k, a, b in zip(("xyz", "scales", "rotations", "opacity", "shs"), hd, ref["deformed_oracle"])}
     return {"frame": "the cpu_baseline frame (same camera, same upstream image gradient)",
+            "factored": ("(A) deformation: HIP outputs vs the deformation oracle, max abs per output below; (B) image / depth / radii / gradients: HIP render() vs "
+                         "the C rasterizer oracle blending the SAME deformed Gaussians, gradients chained through the oracle's deformation (float64) -- "
+                         "a rasterizer fed inputs that differ by 1e-6 may order two near-equal-depth Gaussians the other way, which is no property of "
+                         "either stage (oracle/chain.py)") if ref.get("factored") else "unfactored (oracle chain end to end)",
+            "deformation_max_abs_vs_oracle": stage_a,
             "image_psnr_dB": 10 * math.log10(1.0 / max(mse, 1e-20)), "image_mean_abs": float(np.abs(im - ref["color"]).mean()),
             "image_max_abs": float(np.abs(im - ref["color"]).max()),
             # isolated pixels where a 1/255 or T < 1e-4 decision falls the other way in float rounding (counted, like the ReLU flips

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 
-def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32, both=False):
+def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=False, grad_dtype=torch.float32, both=False, deformed=None):
     """render() restated with the CPU oracles: deformation oracle (pinned to the reference modules) -> C rasterizer oracle
     forward -> L1-loss image gradient against a seeded random target -> C analytic backward -> torch-CPU autograd through the
     deformation.  `pc` is a CPU SynthModel.  Returns (oracle object, dL/dimage, dL/ddepth, {parameter name: gradient or None}).
@@ -20,7 +20,15 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
     with the same (float32-chain) upstream gradients (oracle.deform_oracle.backward_float64) -- THE gradient reference of the full-size
     checks; the returned dict then also carries "__ctx" = (sd, flags, leaves, time, upstream gradients), what oracle.parity.attribute needs
     to name the rows on which an implementation took a ReLU / texel-cell decision the other way.  `both=True` also returns the float32
-    autograd gradients under "__float32" (tools only)."""
+    autograd gradients under "__float32" (tools only).
+    `deformed` (fine stage): (means3D, scales, rotations, opacity, shs) as CPU tensors -- the IMPLEMENTATION's deformed Gaussians.  The C
+    rasterizer oracle then blends THOSE (forward and backward) instead of the deformation oracle's own outputs, and the upstream gradients
+    it returns are chained through the oracle's deformation as before.  Why: the rasterizer takes discrete decisions on its inputs -- above
+    all the front-to-back ORDER of two Gaussians whose view depths differ by less than the deformation's float32 rounding (at 2 M Gaussians
+    there are ~1e5 such pairs; when one of them is large, opaque and overlapping, eight tiles change colour by 0.1 although every input
+    agrees to 1e-6, and which pair flips depends on the summation order of the host's GEMM threads).  Parity is therefore factored:
+    deformation outputs against the deformation oracle (returned under "__deformed" for that comparison), rasterizer against the rasterizer
+    oracle ON THE SAME INPUTS, gradients chained."""
     from oracle import deform_oracle as DO
     from oracle.raster_oracle import RasterOracle
     n = pc._xyz.shape[0]
@@ -36,9 +44,10 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
         m3, sh = leaves["_xyz"], shs
         sc, op = torch.exp(leaves["_scaling"]), torch.sigmoid(leaves["_opacity"])
         rot = torch.nn.functional.normalize(leaves["_rotation"])
-    f = lambda x: np.ascontiguousarray(x.detach().numpy())
+    f = lambda x: np.ascontiguousarray(x.detach().cpu().float().numpy())
     H, W = cam.image_height, cam.image_width
-    o = RasterOracle(means3D=f(m3), scales=f(sc), rotations=f(rot), opacities=f(op), shs=f(sh), viewmatrix=f(cam.world_view_transform),
+    r3, rsc, rrot, rop, rsh = (m3, sc, rot, op, sh) if deformed is None else [d.reshape(t.shape) for d, t in zip(deformed, (m3, sc, rot, op, sh))]
+    o = RasterOracle(means3D=f(r3), scales=f(rsc), rotations=f(rrot), opacities=f(rop), shs=f(rsh), viewmatrix=f(cam.world_view_transform),
                      projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center), bg=np.zeros(3, np.float32), image_height=H,
                      image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
     rng = np.random.default_rng(target_seed)
@@ -63,4 +72,5 @@ def oracle_render_chain(pc, cam, stage="fine", target_seed=0, with_depth_grad=Fa
         g_ref = torch.autograd.grad(outs, wanted, grad_outputs=gouts, allow_unused=True)
         grads = {k: (None if g is None else g.numpy()) for k, g in zip(wnames, g_ref)}
     grads["__means2D"] = go["means2D"]
+    grads["__deformed"] = [t.detach() for t in (m3, sc, rot, op, sh)]      # the deformation oracle's own outputs
     return o, dc, dd, grads

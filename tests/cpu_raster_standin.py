@@ -15,7 +15,7 @@ class _State:
     pass
 
 
-def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None):
+def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None, expect_backward=False):
     f = lambda t: None if (t is None or t.numel() == 0) else np.ascontiguousarray(t.detach().cpu().float().numpy())
     o = RasterOracle(means3D=f(means3D), opacities=f(opacities), viewmatrix=f(settings.viewmatrix), projmatrix=f(settings.projmatrix),
                      campos=f(settings.campos), bg=f(settings.bg), image_height=int(settings.image_height), image_width=int(settings.image_width),

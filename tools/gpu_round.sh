@@ -80,7 +80,16 @@ if f:
         out.append("%-60s %8s %12.3f %10.2f %7s" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
     open("gpurun_out/${TAG}_kernel_stats_shell.txt", "w").write("\n".join(out) + "\n")
 PY
+  if [ -n "$PMC" ]; then   # the two SQ counter sets on the shell scene (long un-terminated lists: where the blending kernels spend their cycles)
+    cd /tmp
+    timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq_shell -o pmc --output-format csv -- python $R/bench.py --scene shell --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    timeout 240 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_sq2_shell -o pmc --output-format csv -- python $R/bench.py --scene shell --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    cd $R
+    python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq_shell gpurun_out/${TAG}_pmc_sq_shell.txt > /dev/null
+    python tools/pmc_summary.py gpurun_out/${TAG}_pmc_sq2_shell gpurun_out/${TAG}_pmc_sq2_shell.txt > /dev/null
+    head -6 gpurun_out/${TAG}_pmc_sq_shell.txt | cut -c1-230
+  fi
 fi
 # drop the bulky raw traces from what travels back (summaries stay)
-rm -rf gpurun_out/${TAG}_prof*/ gpurun_out/${TAG}_pmc_FETCH_SIZE* gpurun_out/${TAG}_pmc_WRITE_SIZE* gpurun_out/${TAG}_pmc_sq/ gpurun_out/${TAG}_pmc_sq2/ 2>/dev/null
+rm -rf gpurun_out/${TAG}_prof*/ gpurun_out/${TAG}_pmc_FETCH_SIZE* gpurun_out/${TAG}_pmc_WRITE_SIZE* gpurun_out/${TAG}_pmc_sq/ gpurun_out/${TAG}_pmc_sq2/ gpurun_out/${TAG}_pmc_sq_shell/ gpurun_out/${TAG}_pmc_sq2_shell/ 2>/dev/null
 exit 0
