@@ -40,6 +40,12 @@
 #ifndef FDGS_NT_SAVE
 #define FDGS_NT_SAVE 1        // the saved activations (written once, read once by the backward ~1 ms later) leave with non-temporal stores:
 #endif                         // +0.2 .. 0.6 % frames/s in the frame, cube and shell scene (profiles/r05_variants_ab_nt_ppl_form.txt; 0 = plain stores)
+#ifndef FDGS_D16_PRIO
+#define FDGS_D16_PRIO 2       // wave priority by phase: 2 = raised OUTSIDE the matrix-core stretches (gather, ReLU / parking, epilogues: the wave
+#endif                         // whose next memory request is on its critical path goes first; the other wave's MFMA chain tolerates the delay):
+                               // D1 -0.5 .. -1.2 %, +0.3 .. 0.8 % frames/s in the frame, four pairs of runs; 1 = raised INSIDE them: slower;
+                               // also raising it around the operand requests of the products: no better (profiles/r05_d1_wave_priority_ab.txt); 0 = off
+#define FDGS_PRIO_MFMA(on) do { if (FDGS_D16_PRIO == 1) __builtin_amdgcn_s_setprio((on) ? 2 : 0); else if (FDGS_D16_PRIO == 2) __builtin_amdgcn_s_setprio((on) ? 0 : 2); } while (0)
 typedef float nt4f_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_saved16(float* dst, const float4& v) {
 #if FDGS_NT_SAVE
@@ -382,7 +388,9 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
         for (int u = 0; u < FU; u++) store_saved16(d.sv_feat + g_row * d.F + 16 * u + 4 * q, feat[u]);
     }
     f32x4 hid[WT16];
+    FDGS_PRIO_MFMA(true);
     T0.run(feat, hid);
+    FDGS_PRIO_MFMA(false);
 #pragma unroll
     for (int t = 0; t < WT16; t++)
 #pragma unroll
@@ -509,8 +517,10 @@ __global__ void __launch_bounds__(256, 2) deform_fwd16_kernel(DeformDev d) {
 #pragma unroll
         for (int oh = 0; oh < OH; oh++) {
             f32x4 y[OG];
+            FDGS_PRIO_MFMA(true);
             if (oh == 0) L1.run_group(0, hid, y, [&](int j) { drain_piece(j); });      // (the previous layer's parked tile leaves under group 0)
             else L1.run_group(oh, hid, y, [&](int) {});
+            FDGS_PRIO_MFMA(false);
             D1_TICK(3);
             // bias + ReLU: register r of k-tile t = 4 oh + c holds feature KT (4q + r) + 4 oh + c
 #pragma unroll
