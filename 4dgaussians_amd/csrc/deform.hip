@@ -2692,7 +2692,10 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             ma.off_dq = o; o += 3 * Gc;
             ma.off_org = o; o += 96 + 9 * Gc;
             const size_t lds_bytes = (size_t)o * 4;
-            int blocks = 256;
+#ifndef FDGS_D4_WGS
+#define FDGS_D4_WGS 256
+#endif
+            int blocks = FDGS_D4_WGS;
             if (blocks > nchunks_max) blocks = nchunks_max;
             const void* fn = p->C == 16 ? reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<16, 8>)
                                         : reinterpret_cast<const void*>(&deform_plane_grad_mfma_kernel<32, 8>);
