@@ -154,7 +154,24 @@ def test_foreign_deformation_module_non_fused_fine_stage():
     # the two branches round the activations differently (fused exp / normalize / sigmoid in the kernel vs torch ops): the images agree to
     # rounding except where that moves an alpha across the 1/255 threshold of the blend -- single pixels, bounded by one blended contribution
     dimg = (a["render"] - b["render"]).abs()
-    assert float(dimg.mean()) < 1e-6 and int((dimg > 1e-5).sum()) <= 12 and float(dimg.max()) < 4e-3, (float(dimg.mean()), int((dimg > 1e-5).sum()), float(dimg.max()))
+    # an entry whose alpha crosses 1/255 contributes alpha * T * colour <= colour / 255 to a pixel channel: the bound on a single outlier is the
+    # largest SH colour of a visible Gaussian (no upper clamp, utils/sh_utils.py:113) over 255 -- not a free constant -- and an outlier must be
+    # isolated (one decision, one Gaussian footprint: a handful of pixels), which a real blending error would not be
+    import ctypes
+    fd = _fd()
+    with torch.no_grad():
+        out = fd.deformation.deform(inner, pc._xyz, pc._scaling, pc._rotation, pc._opacity, shs_dc=pc._features_dc, shs_rest=pc._features_rest,
+                                    time=0.55, activate=True)
+        rs = fd.GaussianRasterizationSettings(152, 200, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=dev), 1.0,
+                                              cam.world_view_transform, cam.full_proj_transform, pc.active_sh_degree, cam.camera_center, False, False)
+        _, radii_, _, st_ = fd.rasterizer.rasterize_forward(rs, out[0], out[4], None, out[3], out[1], out[2], None)
+        pp = ctypes.c_void_p()
+        assert fd._lib.lib().fdgs_geom_field(ctypes.c_void_p(st_.geom.data_ptr()), 5000, 3, ctypes.byref(pp)) == 0
+        rgb = torch.empty(5000 * 4, device=dev)
+        assert ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(rgb.data_ptr()), pp, ctypes.c_size_t(5000 * 16), ctypes.c_int(3)) == 0
+        cmax = max(1.0, float(rgb.reshape(5000, 4)[radii_ > 0, :3].max()))
+    n_out = int((dimg > 1e-5).sum())
+    assert float(dimg.mean()) < 1e-6 and n_out <= 12 and float(dimg.max()) <= 1.05 * cmax / 255.0, (float(dimg.mean()), n_out, float(dimg.max()), cmax)
     for k, v in ga.items():
         k2 = k.replace("_deformation.", "_deformation.inner.")
         assert rel_l2(gb[k2].cpu().numpy(), v.cpu().numpy()) < 1e-4, k
