@@ -621,7 +621,8 @@ def cpu_baseline(fdgs, syn, pc, cam, target, dcfg, frames, deformed=None):
     import numpy as np
     from oracle import deform_oracle as DO
     from oracle import raster_oracle as RO
-    cores = os.cpu_count() or 1
+    # (the cores this process may run on: a rank pinned to its GPU's NUMA node -- parallel.pin_host_thread -- has fewer than the machine)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(cores, int(os.environ.get("FDGS_CPU_THREADS", "64")))
     torch.set_num_threads(threads)
     RO.set_threads(threads)
