@@ -219,6 +219,9 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     cnt.key, cnt.P, cnt.R, cnt.stream = key, P, None, None
     slot = ring[1] = (ring[1] + 1) % _RING
     cnt.addr = ring[0].data_ptr() + 4 * slot
+    for c in pending:          # (a count still in flight in this slot -- 64 forwards old: cannot happen on a live device -- is waited for, never overwritten)
+        if c.addr == cnt.addr:
+            c.value()
     if BINNING != "exact" and (expect_backward or BINNING == "capacity") and seen is not None and P > 0 and len(pending) < _RING - 2:
         cap = (int(seen[0] * CAPACITY_SLACK) + 8192) // 4096 * 4096
         cnt.capacity = cap
