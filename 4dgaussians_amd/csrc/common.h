@@ -63,6 +63,7 @@ struct Tuning {
     int tile_cull;   // FDGS_TILE_CULL   1 = exact tile culling, 0 = the reference's rectangle lists
     int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: 4 (default) | 2 | 0 = the 256-thread form
     int tile_order;  // FDGS_TILE_ORDER  1 = the blending kernels take their tiles heaviest-first (per XCD), 0 = in image order
+    int row_compact; // FDGS_ROW_COMPACT 1 = the deformation backward walks the non-zero ROWS (saved activations + ordered input), 0 = 32-row tiles
 };
 extern Tuning g_tune;
 

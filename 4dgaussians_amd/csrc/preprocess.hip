@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdArgs a) {
             const unsigned long long m = __ballot(nz);
             if (lane == 0) {
                 uint32_t* tl = reinterpret_cast<uint32_t*>(e.G + (size_t)e.Npad * 64) + (n0 >> 5);
-                tl[0] = (uint32_t)(m & 0xffffffffull) != 0u ? 1u : 0u;
-                tl[1] = (uint32_t)(m >> 32) != 0u ? 1u : 0u;
+                tl[0] = (uint32_t)(m & 0xffffffffull);      // (bit r = row r of the tile is non-zero: fdgs_deform_bwd builds its row lists from these)
+                tl[1] = (uint32_t)(m >> 32);
             }
             if (e.tile_flags == 2) { t0_live = (uint32_t)(m & 0xffffffffull) != 0u; t1_live = (uint32_t)(m >> 32) != 0u; }   // dead tiles' rows stay unwritten
         }

@@ -43,11 +43,12 @@ int fdgs_abi_version(void);
  * roofline measurement).  fdgs_timing_report synchronises the device and writes "kernel_name count total_ms" lines. */
 int fdgs_timing_enable(int on);
 int fdgs_timing_report(char* buf, size_t buflen, int reset);
-/* Development / test knobs (ABI 4).  The library holds ONE table of nine integer knobs; it is filled from the environment variables
+/* Development / test knobs (ABI 4; ten since ABI 5).  The library holds ONE table of integer knobs; it is filled from the environment variables
  * FDGS_<NAME> once, when the library is loaded, and afterwards changes only through fdgs_tuning_set -- no entry point reads the
  * environment.  Knobs select between equivalent kernel forms or launch shapes (same results up to summation order), never semantics:
  *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (4 | 2 | 0),
- *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order).
+ *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order), row_compact (1 = the deformation backward walks
+ *   the non-zero rows instead of the non-zero 32-row tiles where it can).
  * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
  * set knobs between frames.  fdgs_tuning_reset restores the load-time values.  See INTEGRATION.md ("Knobs"). */
 int fdgs_tuning_set(const char* name, int value);
@@ -135,10 +136,12 @@ typedef struct fdgs_raster_deform_epilogue {
                                     needs no zero fill of these six arrays -- fdgs_deform_bwd, which runs afterwards, only ever adds to
                                     d_xyz (the HexPlane coordinate gradient) */
     int tile_flags;              /* 1: G is followed by uint32 tile_live[Npad/32] (i.e. at (uint32_t*)(G + Npad*64)), written here:
-                                    tile_live[t] = 1 when any of the 32 packed rows 32t .. 32t+31 has a non-zero entry.  Culled, occluded and
+                                    bit r of tile_live[t] is set when packed row 32t + r has a non-zero entry (a tile is live when its word is
+                                    non-zero; ABI 5: the word is the row mask, it used to be 0 / 1).  Culled, occluded and
                                     off-screen Gaussians get all-zero rows (the reference gives them no gradient either,
                                     gaussian_renderer/__init__.py:134-138); fdgs_deform_bwd (packed_rows_ready = 2) then skips whole tiles of
-                                    them -- bit-exact, a zero row adds exactly zero to every sum.
+                                    them -- exact, a zero row adds exactly zero to every sum -- and, with saved activations on spatially ordered
+                                    input, walks only the non-zero ROWS (tuning knob row_compact).
                                     2: as 1, and the 32 rows of a tile flagged 0 are NOT written (their content is unspecified): the caller
                                     MUST hand G to fdgs_deform_bwd with packed_rows_ready = 3, which never reads them (the one dead tile it
                                     may use as padding is zero-filled there).
@@ -282,7 +285,8 @@ typedef struct fdgs_deform_grads {
 int fdgs_deform_bwd_scratch_bytes(const fdgs_deform_params* p, size_t* bytes);
 int fdgs_deform_bwd(void* stream, const fdgs_deform_params* p, const fdgs_deform_grads* g);
 /* Diagnostics (bench.py's FLOP accounting): after fdgs_deform_bwd on `scratch`, out_host[0] = 32-row tiles the backward processed
- * (tiles with a non-zero packed gradient row, + at most 3 of padding), out_host[1] = tiles in total (Npad / 32),
+ * (tiles with a non-zero packed gradient row, + at most 3 of padding; in the row-list form -- tuning knob row_compact, saved activations,
+ * spatially ordered input -- the 32-row units of the list of non-zero ROWS, padded to whole chunks), out_host[1] = tiles in total (Npad / 32),
  * out_host[2] = plane-gradient chunks processed, out_host[3] = chunks in total.  Synchronises the stream. */
 int fdgs_deform_bwd_live_tiles(void* stream, const fdgs_deform_params* p, const void* scratch, uint32_t* out_host);
 

@@ -498,8 +498,11 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     ws = [(w * mask.reshape([-1] + [1] * (w.dim() - 1))).to(dev) for w in ws]
     monkeypatch.setattr(fd.deformation, "COUNT_LIVE_TILES", True)
     res = {}
-    for skip in ("1", "0"):
-        set_knob("skip_dead", skip)
+    # "rows": the default -- on ordered input with saved activations the backward walks the non-zero ROWS (row_compact = 1: row lists, compact
+    # gradient rows, activations fetched through the list); "1": the 32-row tile lists (row_compact = 0); "0": every tile
+    for skip in ("rows", "1", "0"):
+        set_knob("skip_dead", "0" if skip == "0" else "1")
+        set_knob("row_compact", "1" if skip == "rows" else "0")
         gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
         out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.43, activate=True, ordered=ordered)
         params = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
@@ -508,27 +511,35 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
         res[skip] = (g, fd.deformation.last_live_tiles)
     names = ["xyz", "scales", "rot", "opacity", "shs"] + [k for k, _ in params]
     live, total = res["1"][1][0], res["1"][1][1]
-    print(f"[{cfg} n={n} ordered={ordered}] live tiles {live} of {total}; chunks {res['1'][1][2]} of {res['1'][1][3]}")
+    print(f"[{cfg} n={n} ordered={ordered}] live tiles {live} of {total}; chunks {res['1'][1][2]} of {res['1'][1][3]}; "
+          f"row-list units {res['rows'][1][0]}, chunks {res['rows'][1][2]}")
     assert res["0"][1][0] == res["0"][1][1] == total
     expect = len({i // 32 for i in torch.nonzero(mask).squeeze(1).tolist()})
     assert expect <= live <= expect + 3 and live < 0.5 * total
-    worst = {}
-    for k, a, b in zip(names, res["1"][0], res["0"][0]):
-        if b is None:
-            assert a is None
-            continue
-        worst[k] = rel_l2(a.cpu().numpy(), b.cpu().numpy())
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
-    print("   skip vs no-skip worst rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in top))
-    numel = {k: (0 if b is None else b.numel()) for k, b in zip(names, res["0"][0])}
-    for k, v in worst.items():
-        # a handful of values summed over all Gaussians in a different order (second-layer biases: k <= 48 numbers) carry the
-        # re-association noise un-averaged
-        assert v < (2e-5 if numel[k] <= 64 else 2e-6), (k, v)
-    # rows without an upstream gradient receive exactly the identity-path zeros in both runs
-    dead = (mask == 0).to(dev)
-    for a in res["1"][0][:5]:
-        assert float(a[dead].abs().max()) == 0.0
+    if ordered:     # the row list: the non-zero rows, padded to whole chunks (128 rows, or the plane-gradient chunk where that is larger)
+        nrows = int(mask.sum())
+        chunk = max(128, 2048 // args.kplanes_config["output_coordinate_dim"])
+        assert res["rows"][1][0] == -(-nrows // chunk) * chunk // 32 and res["rows"][1][0] <= live
+    else:           # unordered input keeps the per-corner plane-gradient kernel, which walks Gaussians: tile lists
+        assert res["rows"][1][0] == live
+    for mode in ("rows", "1"):
+        worst = {}
+        for k, a, b in zip(names, res[mode][0], res["0"][0]):
+            if b is None:
+                assert a is None
+                continue
+            worst[k] = rel_l2(a.cpu().numpy(), b.cpu().numpy())
+        top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+        print(f"   skip ({mode}) vs no-skip worst rel-L2: " + ", ".join(f"{k}={v:.2e}" for k, v in top))
+        numel = {k: (0 if b is None else b.numel()) for k, b in zip(names, res["0"][0])}
+        for k, v in worst.items():
+            # a handful of values summed over all Gaussians in a different order (second-layer biases: k <= 48 numbers) carry the
+            # re-association noise un-averaged
+            assert v < (2e-5 if numel[k] <= 64 else 2e-6), (mode, k, v)
+        # rows without an upstream gradient receive exactly the identity-path zeros in every run
+        dead = (mask == 0).to(dev)
+        for a in res[mode][0][:5]:
+            assert float(a[dead].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cfg,n", [("dynerf_default", 9000), ("hypernerf_default", 5000), ("dynerf_default", 40100)])
