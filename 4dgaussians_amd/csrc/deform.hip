@@ -1106,23 +1106,55 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         const int it0 = blockIdx.x * 4 + wave;
         if (it0 < nlive4) ridx_nxt = d.s.rows[(size_t)it0 * 32 + (lane & 31)];
     }
+    // ROWS: the LEFTOVER round split by head.  A tile keeps a wave busy for ~100 us and a launch has 4 x CUs waves: with 1 126 tiles on
+    // 1 024 waves (the bench scene) the kernel takes two tile times although the second round holds 102 tiles.  When the tiles behind the
+    // last full round number at most one per workgroup, workgroup b takes tile nfull + b with its FOUR waves: each wave runs a subset of
+    // the heads (the 48-row SH head alone, the fifth head with the second wave), the partial dhid meet in LDS and wave 0 finishes the tile.
+    unsigned all_heads = 0u, my_heads = 0u;
+    int n_on = 0;
+    {
+        const int ord[FDGS_NUM_HEADS] = {FDGS_HEAD_SHS, FDGS_HEAD_POS, FDGS_HEAD_SCALE, FDGS_HEAD_ROT, FDGS_HEAD_OPACITY};
+#pragma unroll
+        for (int i = 0; i < FDGS_NUM_HEADS; i++)
+            if (p.head_on[ord[i]]) {
+                all_heads |= 1u << ord[i];
+                if ((n_on < 4 ? n_on : 1) == wave) my_heads |= 1u << ord[i];
+                n_on++;
+            }
+    }
+    const int nfull = nlive4 / it_stride * it_stride, nleft = nlive4 - nfull;
+    const bool split = ROWS && n_on > 1 && nleft > 0 && nleft <= (int)gridDim.x;
+    const int n_normal = split ? nfull : nlive4;
+    bool sp_pending = split && (int)blockIdx.x < nleft;
     // (list indices are made wave-uniform BEFORE they address the list: scalar loads.  As vector loads they would join the in-order
     // vmcnt queue behind the prefetched activation rows and every read of the list would wait for those.)
-    for (int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave); it < nlive4; it += it_stride) {
+    for (int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave); ROWS || it < nlive4; it += it_stride) {
+        bool sp = false;       // this iteration is the workgroup's tile of the split round
+        if constexpr (ROWS) {
+            if (it >= n_normal) {
+                if (!sp_pending) break;
+                sp = true; sp_pending = false;
+            }
+        }
+        const unsigned heads_it = sp ? my_heads : all_heads;
+        // (the tile-list kernels keep walking p.head_on: their register allocation is at the edge, 512 registers and 92 bytes of spills)
+        auto nexth = [&](unsigned m, int cur) { if constexpr (ROWS) return next_head_m(m, cur); else return next_head(p.head_on, cur); };
+        if (ROWS && sp && tiles_shared) { __syncthreads(); tiles_shared = false; }     // (a wave without a head in the split round would miss the barrier at the head top)
         // opaque per-iteration copies of the lane coordinates: keeps the (hundreds of) loop-invariant weight addresses
         // from being hoisted out of the tile loop and held in registers across it
         int g = g0, h = h0;
         asm volatile("" : "+v"(g), "+v"(h));
-        const int tile = ROWS ? it : (int)live_list[it];
-        const int tile_next = it + it_stride < nlive4 ? (ROWS ? it + it_stride : (int)live_list[it + it_stride]) : -1;
+        const int tile = sp ? nfull + (int)blockIdx.x : (ROWS ? it : (int)live_list[it]);
+        const int tile_next = !sp && it + it_stride < n_normal ? (ROWS ? it + it_stride : (int)live_list[it + it_stride]) : -1;
         if constexpr (ROWS) {
+            if (sp) ridx_nxt = d.s.rows[(size_t)tile * 32 + (lane & 31)];      // (not requested ahead: one exposed round trip per launch)
             ridx_cur = ridx_nxt & ~ROW_PAD;
             if (tile_next >= 0) ridx_nxt = d.s.rows[(size_t)tile_next * 32 + (lane & 31)];
         }
         const int n0 = tile * 32;  // first Gaussian (ROWS: first list position) of this wave's tile (rows < Npad always exist in scratch)
         const int n_row = n0 + g;
         const int n = n_row < p.N ? n_row : p.N - 1;
-        int hd = next_head(p.head_on, -1);
+        int hd = nexth(heads_it, -1);
         DenseIL<WT, WT, true, FwdPD<WT>::L1, false> L1;
         f32x16 hid[SAVED ? 1 : WT], dhid[WT];
         uint32_t hidmask[WT];   // SAVED: bit r of hidmask[t] = relu(hidden)[t][r] > 0
@@ -1177,7 +1209,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #define FDGS_TV_STORE(j) if (j < WT * 4) { const int e4 = j * 64 + lane, row = e4 / (W / 4), c4 = e4 - row * (W / 4); \
                                           *reinterpret_cast<float4*>(lds + row * STRIDE + 4 * c4) = tv##j; }
         if constexpr (SAVED) {
-            if (!tv_loaded) {
+            if (!tv_loaded && (!ROWS || hd < FDGS_NUM_HEADS)) {
                 if constexpr (ROWS) {
                     const float* tslab = d.sv_h1 + (size_t)d.head_slot[hd] * d.s.Npad * W;
                     const uint32_t ridx_sel = ridx_cur;
@@ -1195,10 +1227,10 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
         // queue and every head paid their HBM latency at its first MFMA: 21 k instead of 18 k cycles per head.)
         auto request_next_rows = [&](int cur_hd) {
             if constexpr (SAVED) {
-                int nx = next_head(p.head_on, cur_hd);
+                int nx = nexth(heads_it, cur_hd);
                 int nn0 = n0;
                 const bool wrap = nx >= FDGS_NUM_HEADS;
-                if (wrap) { nx = next_head(p.head_on, -1); nn0 = tile_next * 32; }
+                if (wrap) { nx = nexth(all_heads, -1); nn0 = tile_next * 32; }
                 const bool have = !wrap || tile_next >= 0;
                 tv_loaded = have && wrap;   // "this wave's next tile finds its first rows already requested"
                 if (have) {
@@ -1229,6 +1261,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             // (loads are unconditional -- columns past the head's k outputs lie inside the scratch buffer -- and zeroed by
             // a select: a conditional load becomes a branch that the compiler sinks to the use, exposing its latency)
             const bool small = small_on && k <= 4;
+            const bool coop_e = !small && k > 32 && !(ROWS && sp);     // (split round: the four waves hold the SAME tile -- the per-wave form below)
             float ga[16];
             float sa0 = 0.f, sa1 = 0.f;   // small path: A-lane 4b+i = G[gaussian b (+16)][output i]
             if (small) {
@@ -1237,7 +1270,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 sa1 = gp[(size_t)16 * GCOLS];
                 sa0 = (lane & 3) < k ? sa0 : 0.f;
                 sa1 = (lane & 3) < k ? sa1 : 0.f;
-            } else if (k <= 32) {   // (the 48-row head takes the cooperative path and loads its rows there)
+            } else if (ROWS ? !coop_e : k <= 32) {   // (the 48-row head takes the cooperative path and loads its rows there)
                 const float* gp = d.s.G + (size_t)(n0 + h) * GCOLS + off + g;
 #pragma unroll
                 for (int s = 0; s < 16; s++) ga[s] = gp[(size_t)2 * s * GCOLS];
@@ -1279,7 +1312,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
 #pragma unroll
                     for (int t = 0; t < WT; t++) mask[t] |= (v.v[t] > 0.f ? 1u : 0u) << r;
                 }
-                if (!(!small && k > 32)) request_next_rows(hd);   // (the cooperative SH block needs the registers first)
+                if (ROWS ? !coop_e : !(!small && k > 32)) request_next_rows(hd);   // (the cooperative SH block needs the registers first)
                 D2_TICK(2);
             }
             DenseT<WT, WT, true, 4> B1;
@@ -1298,7 +1331,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
                 a0 = ldA(0); a1 = ldA(1 < nsteps ? 1 : 0); a2 = ldA(2 < nsteps ? 2 : 0);
                 b0 = ldB(0); b1 = ldB(1 < nsteps ? 1 : 0); b2 = ldB(2 < nsteps ? 2 : 0);   // steps >= nsteps are never consumed
             };
-            const bool coop = !small && k > 32;
+            const bool coop = ROWS ? coop_e : (!small && k > 32);
             if (!coop) early_requests();   // (the cooperative SH block needs the registers: requests follow it)
             __builtin_amdgcn_sched_barrier(0);   // keep these requests ahead of the dW2 block
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1456,9 +1489,28 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
             B1.run(dh1, dhid);
             __builtin_amdgcn_wave_barrier();
             D2_TICK(7);
-            hd = next_head(p.head_on, hd);
+            hd = nexth(heads_it, hd);
             if constexpr (!SAVED) {
                 if (hd < FDGS_NUM_HEADS) { L1.setup(p.w1[hd], p.b1[hd], W, W, g, h); L1.preload(); }
+            }
+        }
+        if constexpr (ROWS) {
+            if (sp) {      // the waves' partial dhid meet in their (idle) LDS tiles; wave 0 sums them and finishes the tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < WT; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) lds[(t * 16 + r) * 64 + lane] = dhid[t][r];
+                __syncthreads();
+                if (wave != 0) continue;      // (the last iteration of this workgroup: everybody meets again at the flush below)
+                const int nsets = n_on < 4 ? n_on : 4;
+                for (int w = 1; w < nsets; w++) {
+#pragma unroll
+                    for (int t = 0; t < WT; t++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) dhid[t][r] += lds_all[w * LD::TILE_FLOATS + (t * 16 + r) * 64 + lane];
+                }
             }
         }
         // relu'(hidden), store for the trunk weight gradient, then dfeat = W0^T dhid
