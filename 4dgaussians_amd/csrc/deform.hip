@@ -1998,19 +1998,33 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
     unsigned long long prof_t = __builtin_amdgcn_s_memtime();
     const unsigned long long prof_t0 = prof_t;
 #endif
-    const int nchunks = (int)as_const(ma.counters)[by_rows ? 6 : 2];
-    const int c_begin = (int)((long long)blockIdx.x * nchunks / gridDim.x);         // contiguous runs of the chunk list: spatial locality
-    const int c_end = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
+    const int nchunks = (int)as_const(ma.counters)[2];
+    int c_begin = (int)((long long)blockIdx.x * nchunks / gridDim.x);         // contiguous runs of the chunk list: spatial locality
+    int c_end = (int)((long long)(blockIdx.x + 1) * nchunks / gridDim.x);
+    // row-list form: every workgroup takes an EQUAL share of the list's entries (rounded to 8), cut into chunks of at most G -- not whole
+    // chunks: 283 chunks on 256 workgroups cost two chunk times, 128 + 16 entries cost about 1.4 (a short chunk runs one sampling pass
+    // and short matrix-core loops)
+    int e0 = 0, e1 = 0;
+    if (by_rows) {
+        const int tot = (int)as_const(ma.counters)[5] * 32;
+        int per = (tot + (int)gridDim.x - 1) / (int)gridDim.x;
+        per = (per + 7) & ~7;
+        e0 = (int)blockIdx.x * per; e0 = e0 < tot ? e0 : tot;
+        e1 = e0 + per < tot ? e0 + per : tot;
+        c_begin = 0; c_end = (e1 - e0 + G - 1) / G;
+    }
     const float tq = p.time_scalar;
     for (int ci = c_begin; ci < c_end; ci++) {
         const int chunk = by_rows ? ci : (int)as_const(ma.chunks)[ci];
-        const int n0 = chunk * G;        // (row-list form: first list position)
+        const int n0 = by_rows ? e0 + ci * G : chunk * G;        // (row-list form: first list position)
+        const int cnt = by_rows ? (e1 - n0 < G ? e1 - n0 : G) : G;      // entries of this chunk
+        const int nb_dyn = by_rows ? (cnt + GPW * NW - 1) / (GPW * NW) : NB;      // sampling passes that hold an entry
         // ---- S0: coordinates -> LDS, per-axis minimum over the chunk (the texel index is monotonic in the coordinate, so the
         // window origin of every level follows from the three minima)
         if (tid >= PGM_T - 40) s_cnt_all[tid - (PGM_T - 40)] = 0;
         if (tid < G) {
             const int n = n0 + tid;
-            const uint32_t ent = by_rows ? ma.rows[n] : 0u;
+            const uint32_t ent = by_rows ? (tid < cnt ? ma.rows[n] : ROW_PAD) : 0u;       // (behind the chunk's end: counts as padding everywhere below)
             if (by_rows) s_row[tid] = ent;
             const int nn = by_rows ? (int)(ent & ~ROW_PAD) : (n < p.N ? n : p.N - 1);
             const bool live = by_rows ? !(ent & ROW_PAD) : (n < p.N && a.tile_live[nn >> 5] != 0u);   // (rows of dead tiles do not stretch the window)
@@ -2043,7 +2057,7 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
             // ---- S: lane = (Gaussian, x-corner, 4 channels): 16-byte texel loads, the per-Gaussian index / weight arithmetic is
             // shared by four channels.  dv -> LDS, coordinate gradient -> LDS, window bookkeeping.
 #pragma nounroll
-            for (int b = 0; b < NB; b++) {
+            for (int b = 0; b < nb_dyn; b++) {
                 const int gl = b * (GPW * NW) + gl_s;
                 const int n = n0 + gl;
                 const bool live = by_rows ? !(s_row[gl] & ROW_PAD) : (n < p.N && a.tile_live[n >> 5] != 0u);     // (a dead tile's DFEAT rows were never written)
@@ -2259,10 +2273,11 @@ __global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) deform_plane_grad_
                         f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4v{0.f, 0.f, 0.f, 0.f};
                         float4 nxa = s_ax[ax * G + gk], nxb = s_ax[ax * G + 4 + gk];
                         float nba = s_dv[(k * G + gk) * C + hf * 16 + il], nbb = s_dv[(k * G + 4 + gk) * C + hf * 16 + il];
-                        for (int ks = 0; ks < G / 4; ks += 2) {
+                        const int ksn = nb_dyn * (GPW * NW) / 4;         // (entries of passes that did not run hold the previous chunk's values)
+                        for (int ks = 0; ks < ksn; ks += 2) {
                             const float4 cxa = nxa, cxb = nxb;
                             const float bva = nba, bvb = nbb;
-                            const int gn = 4 * (ks + 2 < G / 4 ? ks + 2 : ks) + gk;
+                            const int gn = 4 * (ks + 2 < ksn ? ks + 2 : ks) + gk;
                             nxa = s_ax[ax * G + gn]; nxb = s_ax[ax * G + gn + 4];
                             nba = s_dv[(k * G + gn) * C + hf * 16 + il]; nbb = s_dv[(k * G + gn + 4) * C + hf * 16 + il];
                             __builtin_amdgcn_sched_barrier(0);

@@ -35,7 +35,9 @@
 // (tests/test_mfma_layouts.py).
 
 #ifndef FDGS_D16_PD1
-#define FDGS_D16_PD1 2        // operand-request stages in flight per hidden-layer product (3 / 4 do not fit 256 registers without spills)
+#define FDGS_D16_PD1 3        // operand-request stages in flight per hidden-layer product: 3 fit 256 registers since the requests of a packed
+                              // stream are addressed by ONE running lane offset + immediates (fetch below; one offset register per request
+                              // before: 64 registers, and 3 stages spilled); 4 spill.  D1 -1 % (profiles/r05_d1_running_offset_ab.txt)
 #endif
 #ifndef FDGS_NT_SAVE
 #define FDGS_NT_SAVE 1        // the saved activations (written once, read once by the backward ~1 ms later) leave with non-temporal stores:
@@ -102,10 +104,16 @@ struct Dense16 {
         }
         bq = q;
     }
-    __device__ __forceinline__ void fetch(int s, float4* dst) const {
+    __device__ __forceinline__ void fetch(int s, float4* dst) {
         if constexpr (PACKED) {
+            // the stages of a packed stream are requested strictly in order (preload: 0 .. PD - 1, then s + PD behind stage s): a running
+            // lane offset, the OG pieces of a stage as immediates.  Written as `ro[0] + (s * OG + o) * 1024` the compiler materialises one
+            // 32-bit offset register PER REQUEST of a head (it may not fold a constant into a 32-bit lane offset) and keeps all 64 alive.
+            (void)s;
 #pragma unroll
-            for (int o = 0; o < OG; o++) dst[o] = *reinterpret_cast<const float4*>(base + (ro[0] + (uint32_t)((s * OG + o) * 1024)));
+            for (int o = 0; o < OG; o++) dst[o] = *reinterpret_cast<const float4*>(base + (size_t)ro[0] + (size_t)(o * 1024));    // (64-bit sum: the piece folds into the instruction)
+            ro[0] += (uint32_t)(OG * 1024);
+            asm volatile("" : "+v"(ro[0]));
         } else {
             const int hf = s % HV, r = (s / HV) % 4, oh = s / (4 * HV);
 #pragma unroll
