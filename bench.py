@@ -503,8 +503,10 @@ def run(args, make_step=None):
             "config": {"workload": args.workload, "scene": scene, "gaussians": N, "image": [W, H], "deformation": dcfg,
                        "frames_per_step": world, "gaussian_order": args.order, "parallelism": f"frame-parallel x{world}", "num_rendered": R, "visible": V,
                        "backward_live_tiles": {"live": live_tiles, "tiles": all_tiles, "frac": round(live_frac, 4),
-                                               "what": "32-Gaussian tiles with a non-zero gradient row (the others are culled / off-screen / "
-                                                       "occluded: zero rows, skipped bit-exactly by the deformation backward); mean of 8 frames"}},
+                                               "what": "32-row units the deformation backward walked, of the 32-Gaussian tiles there are: units of the list "
+                                                       "of non-zero gradient ROWS (padded to whole chunks) where the row-list form runs -- saved activations, "
+                                                       "ordered input, knob row_compact -- else the tiles with a non-zero row.  The other Gaussians are culled / "
+                                                       "off-screen / occluded: zero rows, which add exactly zero and are skipped; mean of 8 frames"}},
             "roofline": roof, "rooflines": rooflines, "cpu_baseline": cpu, "parity": parity,
             "p10_ms_per_step": _percentile(ms_regions, 0.1), "p90_ms_per_step": _percentile(ms_regions, 0.9),
             "timed_regions": len(regions), "timed_regions_ms_per_step": [round(x, 4) for x in ms_regions], "value_is": "median of the timed regions",
