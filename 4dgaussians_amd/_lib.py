@@ -18,7 +18,7 @@ class RasterParams(Structure):
                 ("debug", c_int), ("bg", c_void_p), ("viewmatrix", c_void_p), ("projmatrix", c_void_p),
                 ("campos", c_void_p), ("means3D", c_void_p), ("shs", c_void_p), ("colors_precomp", c_void_p),
                 ("opacities", c_void_p), ("scales", c_void_p), ("rotations", c_void_p), ("cov3D_precomp", c_void_p),
-                ("visibility", c_void_p)]
+                ("visibility", c_void_p), ("acc_zero", c_void_p)]
 
 
 class RasterDeformEpilogue(Structure):
@@ -32,7 +32,7 @@ class RasterGrads(Structure):
     _fields_ = [("dL_dcolor", c_void_p), ("dL_ddepth", c_void_p), ("dL_dmeans2D", c_void_p), ("dL_dmeans3D", c_void_p),
                 ("dL_dopacity", c_void_p), ("dL_dcolors", c_void_p), ("dL_dsh", c_void_p), ("dL_dscales", c_void_p),
                 ("dL_drotations", c_void_p), ("dL_dcov3D", c_void_p), ("scratch_acc", c_void_p),
-                ("deform_epilogue", POINTER(RasterDeformEpilogue))]
+                ("deform_epilogue", POINTER(RasterDeformEpilogue)), ("scratch_acc_zeroed", c_int)]
 
 
 class DeformParams(Structure):

@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) radix_digit_scan_kernel(uint32_t* __restr
     if (t == 0) dtot[blockIdx.x] = carry;
 }
 
-// Two-level scan of n values (GATHER: value i = src[idx[i]]): (1) every workgroup scans its 4096-value chunk
-// (inclusive) and publishes the chunk total, (2) every workgroup adds the totals of the chunks before it.
+// Scan of n values (GATHER: value i = src[idx[i]]) in 4096-value chunks: every workgroup scans its chunk (inclusive) and publishes the
+// chunk total; the consumer (expand_pairs_kernel) adds the totals of the chunks in front of the one it reads.
 constexpr int SCAN_CHUNK = 4096;
 template <bool GATHER>
 __global__ void __launch_bounds__(256) scan_chunk_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx,
@@ -91,30 +91,6 @@ __global__ void __launch_bounds__(256) scan_chunk_kernel(const uint32_t* __restr
     }
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(256) scan_add_kernel(uint32_t* __restrict__ dst, uint32_t n, const uint32_t* __restrict__ bsum) {
-    __shared__ uint32_t wtmp[4];
-    const uint32_t b = blockIdx.x + 1;  // chunk 0 needs nothing added
-    uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < b; j += 256) part += bsum[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if ((threadIdx.x & 63) == 0) wtmp[threadIdx.x >> 6] = part;
-    __syncthreads();
-    const uint32_t add = wtmp[0] + wtmp[1] + wtmp[2] + wtmp[3];
-    const uint32_t i0 = b * SCAN_CHUNK + threadIdx.x * 16;
-    if (i0 + 16 <= n) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint4 q = reinterpret_cast<uint4*>(dst + i0)[k];
-            q.x += add; q.y += add; q.z += add; q.w += add;
-            reinterpret_cast<uint4*>(dst + i0)[k] = q;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) if (i0 + k < n) dst[i0 + k] += add;
-    }
-}
-
 // ---------------------------------------------------------------- radix histogram: hist[digit*nblocks + block]
 // `n_dev` (capacity mode, fdgs_raster_fwd_capacity): the key count lives on the device -- the launch is sized for the capacity `n`, the
 // kernel works on min(*n_dev, n) keys; blocks behind the end still publish their (zero) counters.
@@ -324,12 +300,16 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
                                                            const uint4* __restrict__ cullmask, const uint32_t* __restrict__ total,
                                                            int gx, uint32_t* __restrict__ pair_tile,
                                                            uint32_t* __restrict__ pair_gid, uint32_t* __restrict__ ranges_zero, uint32_t ranges_n,
-                                                           uint32_t cap /* capacity mode: pairs behind it are dropped (the FARTHEST: pairs come in depth order) */) {
+                                                           uint32_t cap /* capacity mode: pairs behind it are dropped (the FARTHEST: pairs come in depth order) */,
+                                                           const uint32_t* __restrict__ bsum /* totals of the 4096-Gaussian scan chunks: `offsets_incl` is chunk-local */,
+                                                           uint32_t* __restrict__ host_count /* opt (capacity mode): pinned host word that receives the pair count */) {
     // (the per-tile ranges tile_ranges_kernel fills at the end of the stage: cleared here, on the way, instead of by a memset node)
     if (blockIdx.y == 0)
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < ranges_n; k += gridDim.x * 256) ranges_zero[k] = 0u;
     __shared__ uint32_t s_end[256];
     __shared__ uint32_t s_gid[256];
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_cnt0;
     __shared__ uint2 s_rect[256];
     __shared__ uint4 s_mask[256][2];
     const bool culled = total[2] != 0;
@@ -347,15 +327,29 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
         end = offsets_incl[P - 1];
     }
     s_end[t] = end; s_gid[t] = gid; s_rect[t] = rc;
+    if (t == 0) s_cnt0 = cnt;
+    // the scan left chunk-LOCAL inclusive offsets (scan_chunk_kernel): the pairs in front of this block's chunk are the totals of the chunks
+    // before it (the second scan kernel that used to add them to every offset is gone: one launch less)
+    {
+        const int chunk = (blockIdx.x * 256) / SCAN_CHUNK;
+        uint32_t part = 0;
+        for (int j = t; j < chunk; j += 256) part += bsum[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if ((t & 63) == 0) s_part[t >> 6] = part;
+    }
+    if (host_count && blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+        __hip_atomic_store(host_count, total[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (zero-copy: no copy node on the stream)
     __syncthreads();
-    const int first = blockIdx.x * 256;
-    const uint32_t start = (first == 0) ? 0u : offsets_incl[first - 1];
-    const uint32_t stop = s_end[255] < cap ? s_end[255] : cap;
-    (void)cnt;
+    const uint32_t cp = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    // (everything below in chunk-local pair positions; `cp` makes them global where memory is addressed)
+    const uint32_t start = s_end[0] - s_cnt0;          // local offset in front of the block's first Gaussian
+    const uint32_t stop_g = s_end[255] + cp < cap ? s_end[255] + cp : cap;
     // gridDim.y workgroups share one block of 256 depth-consecutive Gaussians and interleave its pairs: the nearest Gaussians (the first
     // blocks) cover 60+ tiles each, five times the average.  Measured: 2 workgroups per block 0.036 ms, 1: 0.042, 4: 0.042, 8: 0.064 (the
     // staging of the 256 Gaussians -- two dependent gathers -- is repeated per workgroup)
-    for (uint32_t p = start + t + 256u * blockIdx.y; p < stop; p += 256u * gridDim.y) {
+    for (uint32_t pg = cp + start + t + 256u * blockIdx.y; pg < stop_g; pg += 256u * gridDim.y) {
+        const uint32_t p = pg - cp;
         // smallest j with s_end[j] > p
         int lo = 0, hi = 255;
 #pragma unroll
@@ -371,8 +365,8 @@ __global__ void __launch_bounds__(256) expand_pairs_kernel(int P, const uint32_t
         uint32_t local = p - jstart;
         if (culled && w * ((r.y >> 16) - ymin) <= 256u) local = nth_set_bit(s_mask[j][0], s_mask[j][1], local);
         const uint32_t ty = ymin + local / w, tx = xmin + local % w;
-        pair_tile[p] = ty * (uint32_t)gx + tx;
-        pair_gid[p] = s_gid[j];
+        pair_tile[pg] = ty * (uint32_t)gx + tx;
+        pair_gid[pg] = s_gid[j];
     }
 }
 
@@ -427,7 +421,8 @@ extern "C" int fdgs_binning_bytes(uint32_t R, int W, int H, size_t* bytes) {
 
 // depth sort + offsets scan; the pair total goes to *num_rendered_host asynchronously.  wait = true: returns when it has arrived (the
 // reference's one blocking read-back), false: never blocks (capacity mode)
-static int bin_prepare_impl(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host, bool wait) {
+// `skip_copy` (capacity mode): the pair count reaches the host word through a store of expand_pairs_kernel (zero-copy), not a copy node
+static int bin_prepare_impl(void* stream_, const fdgs_raster_params* p, void* geom, uint32_t* num_rendered_host, bool wait, bool skip_copy = false) {
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(geom && num_rendered_host, "geom/num_rendered_host is NULL");
@@ -443,7 +438,7 @@ static int bin_prepare_impl(void* stream_, const fdgs_raster_params* p, void* ge
     const int dev_ = current_device_slot();
     hipEvent_t& ev = evs[dev_];
     if (wait && !ev) FDGS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
+    if (!skip_copy) FDGS_HIP_CHECK(hipMemcpyAsync(num_rendered_host, at<uint32_t>(geom, gl.total), 4, hipMemcpyDeviceToHost, stream));
     if (wait) FDGS_HIP_CHECK(hipEventRecord(ev, stream));
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(geom, gl.keys0), at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.keys1),
@@ -460,10 +455,9 @@ static int bin_prepare_impl(void* stream_, const fdgs_raster_params* p, void* ge
         FDGS_TIMED("scan_tiles", stream);
         const int nchunks = cdiv(p->P, SCAN_CHUNK);
         uint32_t* bsum = at<uint32_t>(geom, gl.hist);
+        // (chunk-local offsets + chunk totals: expand_pairs_kernel adds the totals of the chunks in front of its block itself)
         hipLaunchKernelGGL((scan_chunk_kernel<true>), dim3(nchunks), dim3(256), 0, stream, at<uint32_t>(geom, gl.tiles),
                            at<uint32_t>(geom, gl.ids0), at<uint32_t>(geom, gl.offsets), (uint32_t)p->P, bsum);
-        if (nchunks > 1)
-            hipLaunchKernelGGL(scan_add_kernel, dim3(nchunks - 1), dim3(256), 0, stream, at<uint32_t>(geom, gl.offsets), (uint32_t)p->P, bsum);
     }
     {
         hipError_t e_ = hipGetLastError();
@@ -483,7 +477,8 @@ extern "C" int fdgs_bin_prepare(void* stream_, const fdgs_raster_params* p, void
 
 // pair expansion + tile sort + ranges.  from_device: R is the CAPACITY of `binning`; the kernels read the true pair count from the geom
 // buffer and work on min(true, capacity) pairs
-static int bin_sort_impl(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t R, bool from_device) {
+static int bin_sort_impl(void* stream_, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t R, bool from_device,
+                         uint32_t* host_count_dev = nullptr) {
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(geom && img && (binning || R == 0), "geom/binning/img is NULL");
@@ -500,7 +495,7 @@ static int bin_sort_impl(void* stream_, const fdgs_raster_params* p, void* geom,
                        at<uint32_t>(geom, gl.offsets), at<uint32_t>(geom, gl.tiles), at<uint2>(geom, gl.rect), at<uint4>(geom, gl.cullmask),
                        at<uint32_t>(geom, gl.total), il.gx,
                        at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(img, il.ranges), (uint32_t)(il.gx * il.gy * 2),
-                       from_device ? R : 0xFFFFFFFFu); }
+                       from_device ? R : 0xFFFFFFFFu, at<uint32_t>(geom, gl.hist), host_count_dev); }
     FDGS_LAUNCH_CHECK("expand_pairs", p->debug, stream);
     int in = 0;
     rc = radix_sort_pairs(stream, at<uint32_t>(binning, bl.tile0), at<uint32_t>(binning, bl.gid0), at<uint32_t>(binning, bl.tile1),
@@ -528,9 +523,14 @@ extern "C" int fdgs_raster_fwd_capacity(void* stream, const fdgs_raster_params* 
     FDGS_REQUIRE(capacity > 0 && binning, "capacity mode needs a binning buffer of fdgs_binning_bytes(capacity) bytes, capacity > 0");
     int rc = fdgs_preprocess_fwd(stream, p, geom, radii);
     if (rc) return rc;
-    rc = bin_prepare_impl(stream, p, geom, num_rendered_host, false);
+    // the count's way to the host: a store by the expansion kernel into the (pinned, device-visible) word; a copy node if the word is not
+    // device-visible (a 4-byte copy costs the stream 4 us + a launch gap in the middle of the frame)
+    void* dp = nullptr;
+    const bool zero_copy = p->P > 0 && hipHostGetDevicePointer(&dp, num_rendered_host, 0) == hipSuccess && dp != nullptr;
+    if (!zero_copy) (void)hipGetLastError();
+    rc = bin_prepare_impl(stream, p, geom, num_rendered_host, false, zero_copy);
     if (rc) return rc;
-    rc = bin_sort_impl(stream, p, geom, binning, img, capacity, true);
+    rc = bin_sort_impl(stream, p, geom, binning, img, capacity, true, zero_copy ? reinterpret_cast<uint32_t*>(dp) : nullptr);
     if (rc) return rc;
     return fdgs_render_fwd(stream, p, geom, binning, img, capacity, out_color, out_depth);
 }

@@ -131,9 +131,12 @@ struct RenderArgs {
     const float* bg;
     float* final_T; uint32_t* n_contrib;
     float *out_color, *out_depth;
+    float4* zfill; uint32_t zfill_n4;        // opt: a range zero-filled on the way (fdgs_raster_params::acc_zero: the backward's accumulator)
 };
 
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
+    if (a.zfill)     // (the kernel is bound by its arithmetic: ~one 16-byte store per thread rides along for free, and a fill launch is gone)
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.zfill_n4; k += gridDim.x * 256u) a.zfill[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tile = unit_lookup(a.order, a.per_xcd, blockIdx.x, a.gx, a.gy, 1, a.bh);
     if (tile < 0) return;
     __shared__ float4 sA[256], sB[256], sC[256];
@@ -602,6 +605,7 @@ extern "C" int fdgs_render_fwd(void* stream_, const fdgs_raster_params* p, const
     a.bg = p->bg; a.final_T = at<float>(img, il.final_T); a.n_contrib = at<uint32_t>(img, il.n_contrib);
     a.out_color = out_color; a.out_depth = out_depth;
     a.tile_todo = at<uint32_t>(img, il.todo); a.per_xcd = il.per_xcd;
+    a.zfill = reinterpret_cast<float4*>(p->acc_zero); a.zfill_n4 = (uint32_t)p->P * 4u;
     a.order = R > 0 ? make_tile_order(stream, 0, il, img, img) : nullptr;
     {
         FDGS_TIMED("render_fwd", stream);
@@ -628,7 +632,7 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
     const size_t P = (size_t)p->P;
     if (P == 0) return FDGS_OK;
     // the per-Gaussian outputs are written for every Gaussian by preprocess_bwd; only the atomic accumulator needs zeros
-    FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_acc, 0, P * 64, stream));
+    if (!g->scratch_acc_zeroed) FDGS_HIP_CHECK(hipMemsetAsync(g->scratch_acc, 0, P * 64, stream));      // (1: the forward filled it, fdgs_raster_params::acc_zero)
     if (p->cov3D_precomp) {   // scale/rotation gradients do not exist on this path: hand back zeros if buffers were given
         if (g->dL_dscales) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_dscales, 0, P * 12, stream));
         if (g->dL_drotations) FDGS_HIP_CHECK(hipMemsetAsync(g->dL_drotations, 0, P * 16, stream));

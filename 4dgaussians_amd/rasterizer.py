@@ -161,7 +161,15 @@ def _none_if_empty(t):
 class RasterState:
     """Buffers one forward pass leaves behind for its backward (the reference's geom/binning/img buffers).  `capacity` = the pair count
     the binning buffer is laid out for (what the C calls take as num_rendered); `num_rendered` = the true count (waits for it if needed)."""
-    __slots__ = ("params", "geom", "binning", "img", "capacity", "count", "keep", "visibility")
+    __slots__ = ("params", "geom", "binning", "img", "capacity", "count", "keep", "visibility", "acc")
+
+    def take_accumulator(self):
+        """(buffer, zeroed) for fdgs_raster_grads::scratch_acc: the [P,16] accumulator the forward zero-filled on the way (training frames), once;
+        a second backward of the same state gets a fresh buffer that fdgs_raster_bwd fills itself."""
+        acc, self.acc = self.acc, None
+        if acc is not None:
+            return acc, 1
+        return torch.empty(self.params.P, 16, device=self.geom.device), 0
 
     @property
     def num_rendered(self):
@@ -208,6 +216,9 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     vis = torch.empty(P, dtype=torch.bool, device=dev)       # radii > 0, written by the projection kernel (no elementwise launch)
     p.visibility = ptr(vis)
+    # a training frame: the blending forward zero-fills the backward's per-Gaussian accumulator on the way (no fill launch before the backward)
+    acc = torch.empty(P, 16, device=dev) if expect_backward and P > 0 else None
+    p.acc_zero = ptr(acc)
     st = stream_ptr()
     tstate, ring = _thread_state(dev)
     pending = tstate["pending"]
@@ -244,6 +255,7 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     state = RasterState()
     state.params, state.geom, state.binning, state.img, state.capacity, state.count = p, geom, binning, img, cap, cnt
     state.visibility = vis
+    state.acc = acc
     state.keep = (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, bg, view, proj, campos)
     return color, radii, depth, state
 
@@ -263,7 +275,7 @@ def rasterize_backward(state, grad_color, grad_depth=None):
                shs=None if shs is None else torch.empty(P, p.sh_coeffs, 3, device=dev),
                scales=None if scales is None else torch.empty(P, 3, device=dev),
                rotations=None if rotations is None else torch.empty(P, 4, device=dev))
-    scratch = torch.empty(P, 16, device=dev)
+    scratch, g.scratch_acc_zeroed = state.take_accumulator()
     g.dL_dcolor, g.dL_ddepth = ptr(grad_color), ptr(grad_depth)
     g.dL_dmeans2D, g.dL_dmeans3D, g.dL_dopacity = ptr(out["means2D"]), ptr(out["means3D"]), ptr(out["opacities"])
     g.dL_dcolors, g.dL_dsh, g.dL_dscales = ptr(out["colors"]), ptr(out["shs"]), ptr(out["scales"])

@@ -65,7 +65,8 @@ class _FusedRenderFunction(torch.autograd.Function):
         f = lambda t: None if t is None else t.float().contiguous()
         grad_color, grad_depth = f(grad_color), f(grad_depth)
         g = _lib.RasterGrads()
-        g_means2D, acc = torch.empty(P, 3, device=dev), torch.empty(P, 16, device=dev)
+        g_means2D = torch.empty(P, 3, device=dev)
+        acc, g.scratch_acc_zeroed = rstate.take_accumulator()       # (zero-filled by the blending forward of this frame: no fill launch here)
         g.dL_dcolor, g.dL_ddepth, g.dL_dmeans2D, g.scratch_acc = _lib.ptr(grad_color), _lib.ptr(grad_depth), _lib.ptr(g_means2D), _lib.ptr(acc)
         epi = _lib.RasterDeformEpilogue()
         epi.activate, epi.Npad = 1, (P + 127) // 128 * 128
@@ -139,7 +140,8 @@ class _FusedRenderViewsFunction(torch.autograd.Function):
             gc = f(grad_colors[v]) if grad_colors is not None else torch.zeros(3, p.H, p.W, device=dev)
             gd = f(grad_depths[v]) if grad_depths is not None else None
             g = _lib.RasterGrads()
-            gm, acc = torch.empty(P, 3, device=dev), torch.empty(P, 16, device=dev)
+            gm = torch.empty(P, 3, device=dev)
+            acc, g.scratch_acc_zeroed = rstate.take_accumulator()
             g.dL_dcolor, g.dL_ddepth, g.dL_dmeans2D, g.scratch_acc = _lib.ptr(gc), _lib.ptr(gd), _lib.ptr(gm), _lib.ptr(acc)
             epi = _lib.RasterDeformEpilogue()
             epi.activate, epi.Npad = 1, (P + 127) // 128 * 128

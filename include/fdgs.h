@@ -89,6 +89,9 @@ typedef struct fdgs_raster_params {
     const float* cov3D_precomp; /* opt [P,6] */
     uint8_t* visibility;    /* opt [P], written by fdgs_preprocess_fwd: 1 where radii > 0 (the `visibility_filter` render() returns,
                                gaussian_renderer/__init__.py:136) -- saves the caller one elementwise launch per frame */
+    float* acc_zero;        /* opt [P,16] floats (ABI 5): fdgs_render_fwd zero-fills them on the way.  A training frame passes the buffer it will
+                               hand to fdgs_raster_bwd as fdgs_raster_grads::scratch_acc, with scratch_acc_zeroed = 1: the 64 bytes per Gaussian
+                               the blending backward accumulates into are then clean without a fill launch between the loss and the backward */
 } fdgs_raster_params;
 
 /* Stage 1: per-Gaussian projection (frustum cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB).
@@ -167,6 +170,8 @@ typedef struct fdgs_raster_grads {
     float* scratch_acc;
     /* opt: see above (requires shs + scales/rotations inputs, 16 SH coefficients) */
     const fdgs_raster_deform_epilogue* deform_epilogue;
+    int scratch_acc_zeroed;  /* 1: scratch_acc is the buffer the forward of THIS state zero-filled (fdgs_raster_params::acc_zero) and no backward
+                                has used it since; 0: fdgs_raster_bwd fills it */
 } fdgs_raster_grads;
 
 /* Backward of stages 4 and 1 (back-to-front blending gradients, then per-Gaussian chain rule). */
