@@ -998,6 +998,63 @@ __global__ void __launch_bounds__(256) row_gather_kernel(RowGatherArgs a) {
     }
 }
 
+// The same in ONE launch (no rowbase array, no tile_compact_kernel) for sets of up to ROW_LIST_MAX_TILES tiles: a workgroup owns 8 tiles
+// (256 rows) and counts the live rows in front of them itself -- a sum over the row masks of the earlier tiles, at most 64 KB of
+// coalesced reads, skipped by the workgroups without a live row (80 % on the bench scene) -- then lists and copies like row_gather_kernel.
+// The workgroup of the last tiles also leaves the counters and the padding (what tile_compact_kernel does in the two-launch form).
+constexpr int ROW_LIST_MAX_TILES = 16384;
+struct RowListArgs { const uint32_t* flags; const float* G; uint32_t* rows; float* Gc; uint32_t* counters; int ntiles, tpc, row_pad; };
+__global__ void __launch_bounds__(256) row_list_kernel(RowListArgs a) {
+    __shared__ uint8_t lst_all[4][64];
+    __shared__ uint32_t s_part[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int tb = blockIdx.x * 8;                      // first tile of this workgroup (ntiles is a multiple of 4)
+    const bool last = tb + 8 >= a.ntiles;
+    const int t0 = tb + 2 * wv;                         // first tile of this wave
+    const uint32_t m0 = t0 < a.ntiles ? a.flags[t0] : 0u, m1 = t0 + 1 < a.ntiles ? a.flags[t0 + 1] : 0u;
+    const int wcnt = __popc(m0) + __popc(m1);
+    if (!last && __syncthreads_or(wcnt) == 0) return;   // (uniform: a workgroup of dead tiles has nothing to list)
+    uint32_t part = 0;
+    for (int i = t; i < tb; i += 256) part += (uint32_t)__popc(a.flags[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) s_part[wv] = part;
+    __syncthreads();
+    const uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    if (lane == 0) s_part[wv] = (uint32_t)wcnt;
+    __syncthreads();
+    uint32_t b0 = base;
+    for (int w = 0; w < wv; w++) b0 += s_part[w];
+    if (wcnt) {
+        const unsigned long long m = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+        const bool on = (m >> lane) & 1ull;
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        uint8_t* lst = lst_all[wv];
+        if (on) { a.rows[b0 + rank] = (uint32_t)(t0 * 32 + lane); lst[rank] = (uint8_t)lane; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int sub = lane >> 4, c4 = lane & 15;      // four rows per pass: 16 lanes x 16 bytes each
+        const float4* G4 = reinterpret_cast<const float4*>(a.G + (size_t)t0 * 32 * GCOLS);
+        float4* O4 = reinterpret_cast<float4*>(a.Gc + (size_t)b0 * GCOLS);
+        for (int e0 = 0; e0 < wcnt; e0 += 4) {
+            const int e = e0 + sub;
+            if (e < wcnt) O4[e * 16 + c4] = G4[(int)lst[e] * 16 + c4];
+        }
+    }
+    if (last) {      // totals, padding to whole units of row_pad rows, counters (the tile lists are not built: nobody reads them in this form)
+        const uint32_t tr = base + s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const uint32_t rp = (tr + (uint32_t)a.row_pad - 1u) / (uint32_t)a.row_pad * (uint32_t)a.row_pad;
+        for (uint32_t k = tr + t; k < rp; k += 256) a.rows[k] = ROW_PAD;
+        float4* gz = reinterpret_cast<float4*>(a.Gc + (size_t)tr * GCOLS);
+        for (uint32_t k = t; k < (rp - tr) * (GCOLS / 4); k += 256) gz[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t == 0) {
+            a.counters[0] = 0u; a.counters[1] = 0u; a.counters[2] = 0u; a.counters[3] = (uint32_t)a.ntiles;
+            a.counters[4] = tr; a.counters[5] = rp / 32u; a.counters[6] = rp / (32u * (uint32_t)a.tpc);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ D2 backward-data
 struct BwdScratch {
     float *G, *DH1, *DHID, *RH, *FEAT, *DFEAT;
@@ -2717,9 +2774,18 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
             ca.rowbase = reinterpret_cast<uint32_t*>(base + bl.rowbase); ca.rows = reinterpret_cast<uint32_t*>(base + bl.rows); ca.Gc = base + bl.Gc;
             ca.row_pad = Gc > 128 ? Gc : 128;
         }
+        const bool one_launch = by_rows && ca.ntiles <= ROW_LIST_MAX_TILES && g_tune.row_compact != 2;     // (knob value 2: the two-launch form at any size, tests)
+        if (one_launch) {
+            RowListArgs ra{};
+            ra.flags = s.tile_live; ra.G = s.G; ra.rows = ca.rows; ra.Gc = ca.Gc; ra.counters = s.counters; ra.ntiles = ca.ntiles; ra.tpc = ca.tpc; ra.row_pad = ca.row_pad;
+            { FDGS_TIMED("row_list", stream); hipLaunchKernelGGL(row_list_kernel, dim3(cdiv(ca.ntiles, 8)), dim3(256), 0, stream, ra); }
+            FDGS_LAUNCH_CHECK("row_list", 0, stream);
+            s.rows = ca.rows; s.G = ca.Gc;       // (from here on "G" is the compact copy)
+        } else {
         { FDGS_TIMED("tile_compact", stream); hipLaunchKernelGGL(tile_compact_kernel, dim3(1), dim3(1024), 0, stream, ca); }
         FDGS_LAUNCH_CHECK("tile_compact", 0, stream);
-        if (by_rows) {
+        }
+        if (by_rows && !one_launch) {
             RowGatherArgs ra{};
             ra.flags = s.tile_live; ra.rowbase = ca.rowbase; ra.G = s.G; ra.rows = ca.rows; ra.Gc = ca.Gc; ra.ntiles = ca.ntiles;
             { FDGS_TIMED("row_gather", stream); hipLaunchKernelGGL(row_gather_kernel, dim3(cdiv(ca.ntiles, 8)), dim3(256), 0, stream, ra); }

@@ -500,9 +500,10 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     res = {}
     # "rows": the default -- on ordered input with saved activations the backward walks the non-zero ROWS (row_compact = 1: row lists, compact
     # gradient rows, activations fetched through the list); "1": the 32-row tile lists (row_compact = 0); "0": every tile
-    for skip in ("rows", "1", "0"):
+    # "rows2": the row lists built by the two-launch form (tile_compact_kernel + row_gather_kernel: what sets of more than 16 384 tiles take)
+    for skip in ("rows", "rows2", "1", "0"):
         set_knob("skip_dead", "0" if skip == "0" else "1")
-        set_knob("row_compact", "1" if skip == "rows" else "0")
+        set_knob("row_compact", {"rows": "1", "rows2": "2"}.get(skip, "0"))
         gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
         out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.43, activate=True, ordered=ordered)
         params = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
@@ -519,10 +520,10 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     if ordered:     # the row list: the non-zero rows, padded to whole chunks (128 rows, or the plane-gradient chunk where that is larger)
         nrows = int(mask.sum())
         chunk = max(128, 2048 // args.kplanes_config["output_coordinate_dim"])
-        assert res["rows"][1][0] == -(-nrows // chunk) * chunk // 32 and res["rows"][1][0] <= live
+        assert res["rows"][1][0] == res["rows2"][1][0] == -(-nrows // chunk) * chunk // 32 and res["rows"][1][0] <= live
     else:           # unordered input keeps the per-corner plane-gradient kernel, which walks Gaussians: tile lists
-        assert res["rows"][1][0] == live
-    for mode in ("rows", "1"):
+        assert res["rows"][1][0] == res["rows2"][1][0] == live
+    for mode in ("rows", "rows2", "1"):
         worst = {}
         for k, a, b in zip(names, res[mode][0], res["0"][0]):
             if b is None:
