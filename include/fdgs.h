@@ -110,7 +110,8 @@ int fdgs_bin_sort(void* stream, const fdgs_raster_params* p, void* geom, void* b
 /* Stage 4: front-to-back alpha blending per 16x16 tile. out_color [3,H,W], out_depth [1,H,W]. */
 /* Capacity mode (ABI 4): stages 1-4 in ONE call and WITHOUT a host synchronisation.  `binning` holds fdgs_binning_bytes(capacity)
  * bytes for a pair count the caller predicts (e.g. 1.3 x the largest count it has seen); the true count stays on the device -- the kernels
- * work on min(true, capacity) pairs -- and is copied to *num_rendered_host (pinned host memory) asynchronously: pre-set the word to
+ * work on min(true, capacity) pairs -- and reaches *num_rendered_host (pinned host memory) asynchronously (ABI 5: a store of the pair
+ * expansion kernel when the word is device-visible -- hipHostGetDevicePointer --, a copy node otherwise): pre-set the word to
  * 0xFFFFFFFF and read it once it changed (or after the stream passed this call).  true > capacity means the FARTHEST pairs of this frame
  * were dropped (pairs are emitted in depth order): render again with a larger capacity.  The buffers are laid out for `capacity`: pass
  * `capacity` as num_rendered to fdgs_raster_bwd / fdgs_binning_field.  P = 0 writes 0 to the word immediately. */
@@ -185,8 +186,8 @@ int fdgs_mark_visible(void* stream, int P, const float* means3D, const float* vi
 /* Test/diagnostic access to geom fields (device pointers into `geom`):
  * 0 depth f32[P]; 1 recA float4[P] (x,y,conic.xx,conic.xy); 2 recB float4[P] (conic.yy,opacity,depth,0);
  * 3 recC float4[P] (r,g,b,0); 4 cov3D f32[P,6]; 5 tiles_touched u32[P]; 6 clamped u32[P] (bit c = channel c);
- * 7 rect u32[P,2] (xmin|ymin<<16, xmax|ymax<<16); 8 sorted Gaussian ids u32[P]; 9 point_offsets u32[P] (inclusive,
- * depth order). */
+ * 7 rect u32[P,2] (xmin|ymin<<16, xmax|ymax<<16); 8 sorted Gaussian ids u32[P]; 9 point_offsets u32[P] (inclusive, depth
+ * order; ABI 5: LOCAL to chunks of 4096 Gaussians -- the pair expansion adds the totals of the chunks in front itself). */
 int fdgs_geom_field(void* geom, int P, int which, void** ptr);
 /* 0 sorted pair Gaussian ids u32[R]; 1 sorted pair tile ids u32[R]. */
 int fdgs_binning_field(void* binning, uint32_t num_rendered, int W, int H, int which, void** ptr);
