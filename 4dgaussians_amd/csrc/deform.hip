@@ -1734,13 +1734,24 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, const_u32p 
     float bsum[WT];
 #pragma unroll
     for (int a = 0; a < WT; a++) bsum[a] = asum[a] + __shfl_xor(asum[a], 32, 64);
+    // (interleaved columns with WT = 4: the four column tiles of a lane are 16 contiguous bytes -- one ds_write_b128 / ds_read_b128 instead of
+    // four 4-byte accesses at a 16-byte lane stride, which run four-way bank-conflicted)
+    constexpr bool V4 = COLS_IL && CT == 4;
     if (wave == 0) {
+        if constexpr (V4) {
+#pragma unroll
+            for (int a = 0; a < WT; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    *reinterpret_cast<float4*>(&ldsW[(WT * rho(r, h) + a) * LDL + WT * g]) = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+        } else {
 #pragma unroll
         for (int a = 0; a < WT; a++)
 #pragma unroll
             for (int b = 0; b < CT; b++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) ldsW[(WT * rho(r, h) + a) * LDL + (COLS_IL ? WT * g + b : 32 * b + g)] = acc[a][b][r];
+        }
         if (h == 0) {
 #pragma unroll
             for (int a = 0; a < WT; a++) ldsB[WT * g + a] = bsum[a];
@@ -1750,6 +1761,19 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, const_u32p 
 #pragma unroll 1
     for (int turn = 1; turn < 4; turn++) {
         if (wave == turn) {
+            if constexpr (V4) {
+#pragma unroll
+                for (int a = 0; a < WT; a++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float4* q = reinterpret_cast<float4*>(&ldsW[(WT * rho(r, h) + a) * LDL + WT * g]);
+                        float4 v = *q;
+                        v.x += acc[a][0][r]; v.y += acc[a][1][r]; v.z += acc[a][2][r]; v.w += acc[a][3][r];
+                        *q = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // 16 read-add-writes at a time (hoisted ds_reads would spill)
+                }
+            } else
 #pragma unroll
             for (int a = 0; a < WT; a++)
 #pragma unroll
@@ -1770,7 +1794,7 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob& J, int W, const_u32p 
 template <int WT, bool ROWS>
 __global__ void __launch_bounds__(256, 1) deform_wgrad_kernel(WgradArgs a) {
     constexpr int W = WT * 32;
-    __shared__ float lds[W * W + W];
+    __shared__ __attribute__((aligned(16))) float lds[W * W + W];
     // job of this workgroup
     int j = 0;
 #pragma unroll
