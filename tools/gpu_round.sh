@@ -62,7 +62,8 @@ for WL in $EXTRA_WORKLOADS; do
   python -c "
 import json,sys
 d=json.load(open('gpurun_out/${TAG}_bench_$WL.json')); print('$WL', round(d['value'],1), 'frames/s', d['config']['num_rendered'], d['kernels_ms_per_step'])" 2>&1 | cut -c1-500
-  if [ -n "$PMC_EXTRA" ]; then prof_one $WL _$WL > /dev/null; pmc_one $WL _$WL; fi
+  # (PMC_EXTRA=1: counter passes for every extra workload; PMC_EXTRA=<substring>: only for the workloads whose name contains it)
+  if [ -n "$PMC_EXTRA" ] && { [ "$PMC_EXTRA" = "1" ] || [[ "$WL" == *"$PMC_EXTRA"* ]]; }; then prof_one $WL _$WL > /dev/null; pmc_one $WL _$WL; fi
 done
 if [ -n "$SHELL_SCENE" ]; then
   # the second scene statistic (bench.py --scene shell): its own bench line with oracle parity + rocprofv3 kernel stats
