@@ -61,7 +61,7 @@ struct Tuning {
     int d4_mfma;     // FDGS_D4_MFMA     -1 = the caller's order hint picks the plane-gradient kernel, 1 / 0 force the splat / the per-corner form
     int d4_rows_kb;  // FDGS_D4_ROWS_KB  -1 = the time rows get all the LDS that is left; >= 0 caps it (tests: rows that do not fit)
     int tile_cull;   // FDGS_TILE_CULL   1 = exact tile culling, 0 = the reference's rectangle lists
-    int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: 4 (default) | 2 | 0 = the 256-thread form
+    int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: -1 (default) = 2 up to 4 096 tiles, 4 above | 4 | 2 | 0 = the 256-thread form
     int tile_order;  // FDGS_TILE_ORDER  1 = the blending kernels take their tiles heaviest-first (per XCD), 0 = in image order
     int row_compact; // FDGS_ROW_COMPACT 1 = the deformation backward walks the non-zero ROWS (saved activations + ordered input), 0 = 32-row tiles
 };

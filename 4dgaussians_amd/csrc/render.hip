@@ -657,7 +657,10 @@ extern "C" int fdgs_raster_bwd(void* stream_, const fdgs_raster_params* p, const
             // (256-thread form: 128 entries staged per round keeps six workgroups per CU at 25 KB of LDS each)
             const dim3 grid(unit_grid(a.gx, a.gy, 1, a.bh));
             // pixels per lane of the strip form (1 wave per workgroup); 0 = the 256-thread form
-            const int ppl = g_tune.rbwd_ppl;
+            // -1 (default): by image size -- one wave per tile leaves the chip underfilled when the image has fewer tiles than the chip has wave
+            // slots (1 024 SIMDs x 4): two waves per tile then (config 3, 2 040 tiles: blending backward 0.274 -> 0.213 ms; config 2, 2 500
+            // tiles: 0.197 -> 0.187; at 5 440 tiles four pixels per lane win by 10 %, profiles/r05_rbwd_ppl_small_images_ab.txt)
+            const int ppl = g_tune.rbwd_ppl >= 0 ? g_tune.rbwd_ppl : (a.gx * a.gy <= 4096 ? 2 : 4);
             if (ppl == 2 || ppl == 4) {
                 const dim3 sgrid(unit_grid(a.gx, a.gy, 4 / ppl, a.bh));
 #define FDGS_STRIP(D_, P_) hipLaunchKernelGGL((render_bwd_strip_kernel<D_, P_>), sgrid, dim3(64), 0, stream, a)

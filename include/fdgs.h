@@ -46,7 +46,7 @@ int fdgs_timing_report(char* buf, size_t buflen, int reset);
 /* Development / test knobs (ABI 4; ten since ABI 5).  The library holds ONE table of integer knobs; it is filled from the environment variables
  * FDGS_<NAME> once, when the library is loaded, and afterwards changes only through fdgs_tuning_set -- no entry point reads the
  * environment.  Knobs select between equivalent kernel forms or launch shapes (same results up to summation order), never semantics:
- *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (4 | 2 | 0),
+ *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (-1 = by image size | 4 | 2 | 0),
  *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order), row_compact (1 = the deformation backward walks
  *   the non-zero rows instead of the non-zero 32-row tiles where it can; 2 = the same with the row lists built by the two-launch form).
  * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
