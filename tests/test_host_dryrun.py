@@ -31,6 +31,9 @@ class _FakeLib:
             elif name == "fdgs_deform_bwd_live_tiles":
                 for i in range(4):
                     a[3][i] = 1
+            elif name == "fdgs_raster_bwd":
+                g = a[6]
+                self.acc_seen = getattr(self, "acc_seen", []) + [(int(g.scratch_acc or 0), int(g.scratch_acc_zeroed))]
             elif name == "fdgs_last_error":
                 return b""
             elif name == "fdgs_abi_version":
@@ -76,6 +79,27 @@ def test_render_forward_backward_plumbing(fake, fused, monkeypatch):
     # coarse stage and a no-grad forward
     with torch.no_grad():
         fdgs.render(cam, pc, _Pipe(), torch.zeros(3), stage="coarse")
+
+
+def test_backward_accumulator_is_the_one_the_forward_zero_filled_exactly_once(fake):
+    """A training frame allocates the blending backward's [P,16] accumulator at forward time and has fdgs_render_fwd zero-fill it on the way
+    (fdgs_raster_params::acc_zero): the first backward of that state hands it over with scratch_acc_zeroed = 1 (no fill launch), a second
+    backward of the same graph gets a fresh buffer that fdgs_raster_bwd must fill itself; a no-grad frame allocates none."""
+    R = fdgs.rasterizer
+    pc = syn.SynthModel(300, "dynerf_default", seed=1)
+    cam = syn.make_camera(64, 48, theta_deg=10.0, time=0.3)
+    res = fdgs.render(cam, pc, _Pipe(), torch.zeros(3), stage="fine")
+    res["render"].sum().backward(retain_graph=True)
+    res["render"].sum().backward()
+    (a0, z0), (a1, z1) = fake.acc_seen
+    assert a0 != 0 and a1 != 0 and z0 == 1 and z1 == 0
+    st = R.RasterState()
+    st.acc, st.params, st.geom = None, type("P", (), {"P": 5})(), torch.zeros(1)
+    buf, zeroed = st.take_accumulator()
+    assert buf.shape == (5, 16) and zeroed == 0
+    with torch.no_grad():
+        fdgs.render(cam, pc, _Pipe(), torch.zeros(3), stage="fine")
+    assert len(fake.acc_seen) == 2
 
 
 def test_render_views_plumbing(fake):
