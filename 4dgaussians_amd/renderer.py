@@ -256,8 +256,6 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     else:
         raster_settings = viewpoint_camera["camera"]
         frame_time = float(viewpoint_camera["time"])
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
     means2D = screenspace_points
     opacity = pc._opacity
     scales = rotations = cov3D_precomp = None
@@ -282,6 +280,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                        head_on=_deformation._head_on(dn.args), activate=True,
                        save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()), grad=torch.is_grad_enabled(),
                        ordered=_deformation.spatial_order_hint(pc._xyz))
+            if not cfg["grad"]:
+                # no graph will be recorded (render.py:57-70, evaluation): the two stages called directly -- autograd.Function.apply costs
+                # 0.05 ms per frame for its 46 inputs even when it has nothing to record
+                st = _deformation.forward_impl(cfg, frame_time, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
+                                               None, dn.grid.aabb, (*planes, *mlp), False)
+                rendered_image, radii, depth, rstate = _rasterizer.rasterize_forward(raster_settings, st.o_xyz, st.o_sh, None, st.o_op, st.o_sc,
+                                                                                     st.o_rot, None, expect_backward=False)
+                return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": rstate.visibility,
+                        "radii": radii, "depth": depth}
             rendered_image, radii, depth, vis = _FusedRenderFunction.apply(
                 cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
                 dn.grid.aabb, *planes, *mlp)
@@ -317,6 +324,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         colors_precomp = override_color
         shs_final = None
 
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)       # (an nn.Module: only built on the paths that call it)
     rendered_image, radii, depth = rasterizer(
         means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp, opacities=opacity_final,
         scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
