@@ -331,7 +331,8 @@ def test_tile_culling_is_exact(case, monkeypatch):
 @pytest.mark.parametrize("with_depth", [False, True])
 def test_blending_kernel_forms_agree(with_depth, monkeypatch):
     """The blending kernels exist in several shapes selected by development knobs -- backward: one wave per tile with four pixels per
-    lane (default), two waves with two pixels per lane (rbwd_ppl = 2), the 256-thread form of rounds 1-2 (rbwd_ppl = 0).  All of them
+    lane (rbwd_ppl = 4: what images of more than 4 096 tiles take by default), two waves with two pixels per lane (rbwd_ppl = 2: the default
+    below that, i.e. for every image of this file), the 256-thread form of rounds 1-2 (rbwd_ppl = 0).  All of them
     must produce the same gradients up to the association of the sums (and the forward, which has one form, the same image every time)."""
     dev = torch.device("cuda:0")
     sc = raster_scene(6000, 232, 152, seed=11, scale_boost=2.0)
@@ -340,7 +341,7 @@ def test_blending_kernel_forms_agree(with_depth, monkeypatch):
     wc = torch.tensor(rng.standard_normal((3, 152, 232)).astype(np.float32), device=dev)
     wd = torch.tensor(rng.standard_normal((1, 152, 232)).astype(np.float32), device=dev)
     outs = {}
-    for name, ppl in (("default", 4), ("bwd2", 2), ("bwd0", 0)):
+    for name, ppl in (("default", 4), ("bwd2", 2), ("bwd0", 0)):      # ("default": the reference leg of the comparison below)
         set_knob("rbwd_ppl", ppl)
         t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
         means2D = torch.zeros_like(t["means3D"], requires_grad=True)
