@@ -103,6 +103,7 @@ SYMBOLS = {
     "fdgs_bin_sort": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32]),
     "fdgs_render_fwd": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "fdgs_raster_fwd_capacity": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdgs_pair_count_wait": (c_int, [c_void_p, c_void_p, POINTER(c_uint32)]),
     "fdgs_raster_bwd": (c_int, [c_void_p, POINTER(RasterParams), c_void_p, c_void_p, c_void_p, c_uint32, POINTER(RasterGrads)]),
     "fdgs_mark_visible": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdgs_geom_field": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
@@ -129,6 +130,8 @@ SYMBOLS = {
     "fdgs_densify_apply": (c_int, [c_void_p, POINTER(GaussiansIn), POINTER(GaussiansOut), c_void_p, c_void_p]),
 }
 
+ABI_VERSION = 6       # what this Python host was written against (include/fdgs.h); checked when the library is loaded
+
 _lib = None
 
 
@@ -147,6 +150,10 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        have = l.fdgs_abi_version()
+        if have != ABI_VERSION:     # structs grow at their end between versions: a stale .so would read past what this host fills in
+            raise FdgsError(f"{LIB_PATH} has ABI {have}, this Python host needs ABI {ABI_VERSION}: rebuild it "
+                            "(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = l
     return _lib
 

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(L1S_THREADS) l1_stats_kernel(size_t n, size_t 
 using namespace fdgs;
 
 extern "C" const char* fdgs_last_error(void) { return g_err; }
-extern "C" int fdgs_abi_version(void) { return 5; }
+extern "C" int fdgs_abi_version(void) { return 6; }
 
 extern "C" int fdgs_tuning_set(const char* name, int value) {
     const KnobDesc* k = find_knob(name);

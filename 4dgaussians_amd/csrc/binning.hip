@@ -403,6 +403,8 @@ int validate_raster_params(const fdgs_raster_params* p);
 
 using namespace fdgs;
 
+int fdgs_preprocess_fwd_impl(void* stream_, const fdgs_raster_params* p, void* geom, int32_t* radii, uint32_t* host_count_dev);   // preprocess.hip
+
 extern "C" int fdgs_geom_bytes(int P, size_t* bytes) {
     FDGS_REQUIRE(P >= 0 && bytes, "bad arguments");
     *bytes = geom_layout(P).bytes;
@@ -521,18 +523,44 @@ extern "C" int fdgs_bin_sort(void* stream_, const fdgs_raster_params* p, void* g
 extern "C" int fdgs_raster_fwd_capacity(void* stream, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t capacity,
                                         uint32_t* num_rendered_host, int32_t* radii, float* out_color, float* out_depth) {
     FDGS_REQUIRE(capacity > 0 && binning, "capacity mode needs a binning buffer of fdgs_binning_bytes(capacity) bytes, capacity > 0");
-    int rc = fdgs_preprocess_fwd(stream, p, geom, radii);
-    if (rc) return rc;
-    // the count's way to the host: a store by the expansion kernel into the (pinned, device-visible) word; a copy node if the word is not
-    // device-visible (a 4-byte copy costs the stream 4 us + a launch gap in the middle of the frame)
+    // the count's way to the host: a store by the LAST workgroup of the projection kernel into the (pinned, device-visible) word -- it is in
+    // host memory while the depth sort is still running; a copy node if the word is not device-visible (a 4-byte copy costs the stream
+    // 4 us + a launch gap in the middle of the frame)
     void* dp = nullptr;
-    const bool zero_copy = p->P > 0 && hipHostGetDevicePointer(&dp, num_rendered_host, 0) == hipSuccess && dp != nullptr;
+    const bool zero_copy = p && p->P > 0 && hipHostGetDevicePointer(&dp, num_rendered_host, 0) == hipSuccess && dp != nullptr;
     if (!zero_copy) (void)hipGetLastError();
+    int rc = fdgs_preprocess_fwd_impl(stream, p, geom, radii, zero_copy ? reinterpret_cast<uint32_t*>(dp) : nullptr);
+    if (rc) return rc;
     rc = bin_prepare_impl(stream, p, geom, num_rendered_host, false, zero_copy);
     if (rc) return rc;
-    rc = bin_sort_impl(stream, p, geom, binning, img, capacity, true, zero_copy ? reinterpret_cast<uint32_t*>(dp) : nullptr);
+    rc = bin_sort_impl(stream, p, geom, binning, img, capacity, true, nullptr);
     if (rc) return rc;
     return fdgs_render_fwd(stream, p, geom, binning, img, capacity, out_color, out_depth);
+}
+
+// Host side of the verified capacity path: wait until the pair count of a frame queued by fdgs_raster_fwd_capacity has reached its pinned
+// host word (0xFFFFFFFF = not yet).  Spins on the word (it arrives with the projection kernel, long before the frame ends); every ~50 us
+// the stream is queried so that a frame that finished without delivering a count is an error instead of a hang.
+extern "C" int fdgs_pair_count_wait(void* stream_, const uint32_t* num_rendered_host, uint32_t* value) {
+    FDGS_REQUIRE(num_rendered_host && value, "NULL pointer");
+    const volatile uint32_t* w = num_rendered_host;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (unsigned spins = 1;; spins++) {
+        const uint32_t v = *w;
+        if (v != 0xFFFFFFFFu) { *value = v; return FDGS_OK; }
+        if ((spins & 0x3FFu) == 0) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) {
+                const uint32_t v2 = *w;
+                if (v2 != 0xFFFFFFFFu) { *value = v2; return FDGS_OK; }
+                return fail(FDGS_E_INVALID, "%s", "the stream is idle and no pair count has arrived: was the frame queued with fdgs_raster_fwd_capacity on this stream?");
+            }
+            if (e != hipErrorNotReady) return fail(FDGS_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 extern "C" int fdgs_geom_field(void* geom, int P, int which, void** ptr) {

@@ -27,7 +27,7 @@ struct PreFwdArgs {
     float tanfovx, tanfovy, scale_mod;
     const float *view, *proj, *campos, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float* depth; float4 *recA, *recB, *recC; float* cov3D;
-    uint32_t *tiles, *clamped; uint2* rect; uint32_t *keys, *ids, *total;
+    uint32_t *tiles, *clamped; uint2* rect; uint32_t *keys, *ids, *total, *host_count;
     int32_t* radii;
     uint8_t* visibility;         // opt: radii > 0
     int cull; uint4* cullmask;   // exact tile culling (gs_math.h): 256-bit tile mask per Gaussian, two uint4 each
@@ -135,7 +135,16 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreFwdArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(a.total, t);
+        if (!a.host_count) {
+            if (t) atomicAdd(a.total, t);
+        } else {
+            // capacity mode: the pair count goes to the host the moment it exists.  total[0] (pairs) and total[1] (workgroups done) are ONE
+            // 64-bit counter: the workgroup whose add completes it knows the final count and stores it into the pinned, device-visible
+            // host word (system scope) -- the host can size / verify the binning buffer while the depth sort is still running
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(a.total), (1ull << 32) | (unsigned long long)t);
+            if ((uint32_t)(old >> 32) == gridDim.x - 1)
+                __hip_atomic_store(a.host_count, (uint32_t)old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (i == 0) a.total[2] = a.cull ? 1u : 0u;   // the pair expansion reads which list semantics the counts have
 }
@@ -470,7 +479,8 @@ int validate_raster_params(const fdgs_raster_params* p) {
 
 using namespace fdgs;
 
-extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, void* geom, int32_t* radii) {
+// host_count_dev (capacity mode): device address of the pinned host word that receives the pair count from the kernel's last workgroup
+int fdgs_preprocess_fwd_impl(void* stream_, const fdgs_raster_params* p, void* geom, int32_t* radii, uint32_t* host_count_dev) {
     int rc = validate_raster_params(p);
     if (rc) return rc;
     FDGS_REQUIRE(geom && (radii || p->P == 0), "geom/radii is NULL");
@@ -489,9 +499,14 @@ extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, v
     a.clamped = at<uint32_t>(geom, gl.clamped); a.rect = at<uint2>(geom, gl.rect); a.keys = at<uint32_t>(geom, gl.keys0);
     a.ids = at<uint32_t>(geom, gl.ids0); a.total = at<uint32_t>(geom, gl.total); a.radii = radii; a.visibility = p->visibility;
     a.cull = g_tune.tile_cull != 0; a.cullmask = at<uint4>(geom, gl.cullmask);
+    a.host_count = host_count_dev;
     { FDGS_TIMED("preprocess_fwd", stream); hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p->P, 256)), dim3(256), 0, stream, a); }
     FDGS_LAUNCH_CHECK("preprocess_fwd", p->debug, stream);
     return FDGS_OK;
+}
+
+extern "C" int fdgs_preprocess_fwd(void* stream_, const fdgs_raster_params* p, void* geom, int32_t* radii) {
+    return fdgs_preprocess_fwd_impl(stream_, p, geom, radii, nullptr);
 }
 
 // called from fdgs_raster_bwd (render.hip)

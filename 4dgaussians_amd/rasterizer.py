@@ -48,29 +48,36 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # ---- pair-count bookkeeping of the binning stage -------------------------------------------------------------------------------------
 # The reference's rasterizer reads the number of (tile, Gaussian) pairs back to the host in the middle of every forward (to size its
-# binning buffer) and the host waits for it.  For TRAINING frames (a backward will follow) that read-back is taken off the critical path:
-# once a pair count has been seen for (image size, number of Gaussians), the binning buffer is sized for a CAPACITY predicted from the
-# largest count seen so far (x CAPACITY_SLACK) and the whole forward is ONE non-blocking C call (fdgs_raster_fwd_capacity); the true count
-# arrives in pinned host memory some time later and is looked at when the NEXT frame starts: it feeds the predictor, and a count above the
-# capacity raises a RuntimeWarning, is counted in `capacity_overflows`, and enlarges the capacity from then on.  An overflowing frame has
-# dropped its FARTHEST pairs -- forward and backward alike, so its gradient is the exact gradient of the image it returned -- which a
-# training loop absorbs like any other per-iteration noise; a frame whose image is the product (no backward expected: evaluation,
-# render.py, the metrics of training_report) ALWAYS takes the blocking exact path, as does the first frame of a (size, count) pair and
-# every frame with BINNING = "exact" (FDGS_BINNING=exact).  BINNING = "capacity" uses the capacity path for evaluation frames too.
+# binning buffer), with nothing queued behind the read: host and device wait for each other once per frame.  Here, once a pair count has
+# been seen for (image size, number of Gaussians), the binning buffer is sized for a CAPACITY predicted from the largest count seen so far
+# (x CAPACITY_SLACK) and the whole forward is queued by ONE C call (fdgs_raster_fwd_capacity).  BINNING selects what happens next:
+#
+#   "auto" (default)   VERIFIED: the host waits for the frame's pair count -- it reaches pinned host memory with the projection kernel, while
+#                      the depth sort, the tile sort and the blending kernel are still queued, so the device does not drain -- and, if the
+#                      count exceeds the capacity, finishes the frame EXACTLY (fdgs_bin_sort + fdgs_render_fwd on a buffer of the true size;
+#                      stages 1-2 are complete in `geom`) before it returns.  No image that differs from the exact path ever leaves
+#                      rasterize_forward (the reference never truncates a list: SURVEY Appendix B.2); `capacity_reruns` counts such frames.
+#   "exact"            the reference's shape: four C calls, the blocking read-back between stage 2 and 3 (FDGS_BINNING=exact).  Also the
+#                      first frame of every (size, count) pair in the other modes.
+#   "capacity"         OPT-IN, never waits: the count is looked at when a later frame starts; a frame whose count exceeded its capacity has
+#                      dropped its FARTHEST pairs -- forward and backward alike, so its gradient is the exact gradient of the image it
+#                      returned -- raises a RuntimeWarning and is counted in `capacity_overflows`.  For loops that prefer a host that runs
+#                      a full frame ahead over the guarantee (the frame is then NOT the reference's).
 # State is per host thread (threading.local): one thread drives a stream, as include/fdgs.h requires.
 BINNING = os.environ.get("FDGS_BINNING", "auto")
 CAPACITY_SLACK = 1.5
-capacity_overflows = 0
+capacity_overflows = 0        # "capacity" mode: frames that dropped pairs
+capacity_reruns = 0           # "auto" mode: frames finished exactly after their speculative capacity proved too small
 _SENTINEL = 0xFFFFFFFF
 _RING = 64
 _tls = threading.local()
-_seen = {}            # (device index, W, H) -> [largest pair count seen, P it was seen at]
+_seen = {}            # (device index, W, H, P) -> [largest pair count seen, P it was seen at]
 _size_cache = {}      # ("geom", P) / ("img", W, H) / ("bin", R) -> bytes
 
 
 class PairCount:
-    """The pair count of one forward: known at once on the exact path, later on the capacity path (`value()` waits for it)."""
-    __slots__ = ("addr", "capacity", "key", "P", "R", "stream")
+    """The pair count of one forward: known at once on the exact and verified paths, later in "capacity" mode (`value()` waits for it)."""
+    __slots__ = ("addr", "capacity", "key", "P", "R", "stream", "buf")
 
     def poll(self):
         if self.R is None:
@@ -98,9 +105,9 @@ def _note_count(c):
         e[0] = max(e[0], c.R)
     if c.capacity is not None and c.R > c.capacity:
         capacity_overflows += 1
-        warnings.warn(f"fdgs rasterizer: a frame listed {c.R} (tile, Gaussian) pairs but its binning buffer was sized for {c.capacity}: the "
-                      f"farthest {c.R - c.capacity} pairs of that frame were dropped; the capacity grows from the next frame on "
-                      "(FDGS_BINNING=exact restores the blocking exact path)", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"fdgs rasterizer (BINNING='capacity'): a frame listed {c.R} (tile, Gaussian) pairs but its binning buffer was sized for "
+                      f"{c.capacity}: the farthest {c.R - c.capacity} pairs of that frame were dropped; the capacity grows from the next frame on "
+                      "(the default BINNING='auto' finishes such a frame exactly instead)", RuntimeWarning, stacklevel=3)
 
 
 def _thread_state(dev):
@@ -179,7 +186,8 @@ class RasterState:
 def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, out=None, expect_backward=False):
     """Runs stages 1-4 of include/fdgs.h. Returns (color, radii, depth, state).  `out` = (color [3,H,W], radii [P] int32, depth [1,H,W])
     buffers to write into (contiguous float32 / int32 on the device), e.g. slices of a batch tensor.  `expect_backward`: a training frame
-    (may take the non-blocking capacity path, see above); False = the image is the product: always the blocking exact path."""
+    (the blending forward zero-fills the backward's accumulator on the way).  Which binning path runs: BINNING above -- every mode but the
+    opt-in "capacity" returns the exact path's image."""
     L = _lib.lib()
     dev = means3D.device
     if not _is_hip_device(dev):
@@ -228,19 +236,35 @@ def rasterize_forward(settings, means3D, shs, colors_precomp, opacities, scales,
     seen = _seen.get(key)
     cnt = PairCount()
     cnt.key, cnt.P, cnt.R, cnt.stream = key, P, None, None
+    cnt.buf = ring[0]                    # (keeps the pinned ring alive for as long as anything may read or write this word)
     slot = ring[1] = (ring[1] + 1) % _RING
     cnt.addr = ring[0].data_ptr() + 4 * slot
     for c in pending:          # (a count still in flight in this slot -- 64 forwards old: cannot happen on a live device -- is waited for, never overwritten)
         if c.addr == cnt.addr:
             c.value()
-    if BINNING != "exact" and (expect_backward or BINNING == "capacity") and seen is not None and P > 0 and len(pending) < _RING - 2:
+    speculative = BINNING == "auto" or (BINNING == "capacity" and len(pending) < _RING - 2)
+    if speculative and seen is not None and P > 0:
+        global capacity_reruns
         cap = (int(seen[0] * CAPACITY_SLACK) + 8192) // 4096 * 4096
-        cnt.capacity = cap
-        cnt.stream = _current_stream(dev)
         ctypes.c_uint32.from_address(cnt.addr).value = _SENTINEL
         binning = torch.empty(_bytes(L, "bin", cap, W, H), dtype=torch.uint8, device=dev)
         check(L.fdgs_raster_fwd_capacity(st, p, ptr(geom), ptr(binning), ptr(img), cap, _lib.c_void_p(cnt.addr), ptr(radii), ptr(color), ptr(depth)))
-        pending.append(cnt)
+        if BINNING == "capacity":      # opt-in: never waits; the count is looked at when a later frame starts
+            cnt.capacity = cap
+            cnt.stream = _current_stream(dev)
+            pending.append(cnt)
+        else:                          # verified: the image this call returns is the exact path's
+            true_n = _lib.c_uint32()
+            check(L.fdgs_pair_count_wait(st, _lib.c_void_p(cnt.addr), true_n))
+            cnt.capacity = None
+            cnt.R = true_n.value
+            _note_count(cnt)
+            if cnt.R > cap:            # the speculative frame dropped pairs: finish it exactly (stages 1-2 are complete in `geom`)
+                capacity_reruns += 1
+                cap = cnt.R
+                binning = torch.empty(_bytes(L, "bin", cap, W, H), dtype=torch.uint8, device=dev)
+                check(L.fdgs_bin_sort(st, p, ptr(geom), ptr(binning), ptr(img), cap))
+                check(L.fdgs_render_fwd(st, p, ptr(geom), ptr(binning), ptr(img), cap, ptr(color), ptr(depth)))
     else:
         check(L.fdgs_preprocess_fwd(st, p, ptr(geom), ptr(radii)))
         check(L.fdgs_bin_prepare(st, p, ptr(geom), _lib.c_void_p(cnt.addr)))          # (blocks until the count is in host memory)

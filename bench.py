@@ -522,9 +522,11 @@ def run(args, make_step=None):
                     "achieved_TFLOPs_in_mfma_kernels": (sum(mfma_flops.values()) / (sum(kern[k]["ms_per_step"] for k in mfma_flops if k in kern) * 1e-3) / 1e12)
                     if kern else None, "peak_TFLOPs": MFMA_F32_PEAK / 1e12},
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            "binning": {"mode": fdgs.rasterizer.BINNING, "capacity_slack": fdgs.rasterizer.CAPACITY_SLACK, "capacity_overflows": fdgs.rasterizer.capacity_overflows,
-                        "what": "training frames size the binning buffer from the largest pair count seen for (image size, Gaussian count) x slack and run "
-                                "the rasterizer forward as one non-blocking call; an overflowing frame would drop its farthest pairs and is counted here"},
+            "binning": {"mode": fdgs.rasterizer.BINNING, "capacity_slack": fdgs.rasterizer.CAPACITY_SLACK, "capacity_overflows": fdgs.rasterizer.capacity_overflows, "capacity_reruns": fdgs.rasterizer.capacity_reruns,
+                        "what": "frames size the binning buffer from the largest pair count seen for (image size, Gaussian count) x slack and queue the "
+                                "rasterizer forward with one call; mode auto (default) waits for the frame's pair count (it arrives with the projection "
+                                "kernel, the rest of the frame stays queued) and finishes an overflowing frame exactly before returning (capacity_reruns); "
+                                "mode capacity (opt-in) never waits and would drop the farthest pairs of an overflowing frame (capacity_overflows)"},
             "gpu_kernel_ms_per_step": round(kernel_sum, 4),
             "loss": {"l1": float(l1), "psnr": float(psnr)},
         }

@@ -109,14 +109,21 @@ int fdgs_bin_sort(void* stream, const fdgs_raster_params* p, void* geom, void* b
 
 /* Stage 4: front-to-back alpha blending per 16x16 tile. out_color [3,H,W], out_depth [1,H,W]. */
 /* Capacity mode (ABI 4): stages 1-4 in ONE call and WITHOUT a host synchronisation.  `binning` holds fdgs_binning_bytes(capacity)
- * bytes for a pair count the caller predicts (e.g. 1.3 x the largest count it has seen); the true count stays on the device -- the kernels
- * work on min(true, capacity) pairs -- and reaches *num_rendered_host (pinned host memory) asynchronously (ABI 5: a store of the pair
- * expansion kernel when the word is device-visible -- hipHostGetDevicePointer --, a copy node otherwise): pre-set the word to
- * 0xFFFFFFFF and read it once it changed (or after the stream passed this call).  true > capacity means the FARTHEST pairs of this frame
- * were dropped (pairs are emitted in depth order): render again with a larger capacity.  The buffers are laid out for `capacity`: pass
- * `capacity` as num_rendered to fdgs_raster_bwd / fdgs_binning_field.  P = 0 writes 0 to the word immediately. */
+ * bytes for a pair count the caller predicts (e.g. 1.5 x the largest count it has seen); the true count stays on the device -- the kernels
+ * work on min(true, capacity) pairs -- and reaches *num_rendered_host (pinned host memory) asynchronously (ABI 6: a store of the LAST
+ * workgroup of the projection kernel when the word is device-visible -- hipHostGetDevicePointer --, i.e. while the depth sort is still
+ * running; a copy node otherwise): pre-set the word to 0xFFFFFFFF and read it once it changed (fdgs_pair_count_wait).  true > capacity
+ * means the FARTHEST pairs of this frame were dropped (pairs are emitted in depth order) and the image is NOT the reference's: the
+ * stage-1/2 results in `geom` are complete and valid, so the caller finishes the frame exactly with fdgs_bin_sort + fdgs_render_fwd on a
+ * buffer of fdgs_binning_bytes(true) bytes (what the Python host does before it hands the image to anyone: the reference never truncates,
+ * SURVEY Appendix B.2).  The buffers are laid out for `capacity`: pass `capacity` as num_rendered to fdgs_raster_bwd /
+ * fdgs_binning_field.  P = 0 writes 0 to the word immediately. */
 int fdgs_raster_fwd_capacity(void* stream, const fdgs_raster_params* p, void* geom, void* binning, void* img, uint32_t capacity,
                              uint32_t* num_rendered_host, int32_t* radii, float* out_color, float* out_depth);
+/* ABI 6: waits (spinning on the pinned word, no hipStreamSynchronize) until the pair count of a frame queued by fdgs_raster_fwd_capacity on
+ * `stream` has arrived, and returns it in *value.  The rest of the frame stays queued behind it, so the device does not drain while the
+ * host looks at the count.  Error if the stream runs idle without a count (wrong stream / word). */
+int fdgs_pair_count_wait(void* stream, const uint32_t* num_rendered_host, uint32_t* value);
 int fdgs_render_fwd(void* stream, const fdgs_raster_params* p, const void* geom, const void* binning, void* img,
                     uint32_t num_rendered, float* out_color, float* out_depth);
 

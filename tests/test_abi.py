@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
         assert hasattr(lib, n), n
         assert n in L.SYMBOLS, f"{n} declared in fdgs.h but not bound in _lib.SYMBOLS"
     assert sorted(L.SYMBOLS) == names
-    assert lib.fdgs_abi_version() == 5
+    assert lib.fdgs_abi_version() == 6
 
 
 def test_host_only_size_queries(L):

@@ -178,3 +178,34 @@ def test_densify_reorders_the_grown_set_along_the_curve(monkeypatch):
         sa, sb = a.optimizer.state[getattr(a, ATTR[n])], b.optimizer.state[getattr(b, ATTR[n])]
         assert torch.equal(sa["exp_avg"][perm], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"][perm], sb["exp_avg_sq"])
     assert torch.equal(a._deformation_table[perm], b._deformation_table)
+
+
+@pytest.mark.parametrize("n,seed", [(3000, 11), (300000, 12)])
+def test_densify_twice_from_cloned_state_is_bit_identical_without_a_sync(n, seed):
+    """fdgs.densify.densify is a deterministic function of its inputs (scan-based destinations, no atomics on rows): twice from cloned state
+    -> bit-identical Parameters, Adam moments and side arrays.  The second result is compared on the stream straight after the apply launch
+    (no torch.cuda.synchronize() in between, other work queued behind it): a result that needed a sync to become visible would differ."""
+    st = DO.random_state(n, seed, sh_rest=15)
+    normals = torch.randn(2 * n, 3, generator=torch.Generator().manual_seed(seed)).cuda()
+    a, b = model_from_state(st), model_from_state(st)
+    ra = dn.densify(a, 0.0002, 0.005, 3.0, 20, normals=normals)
+    torch.cuda.synchronize()
+    filler = torch.randn(1 << 22, device="cuda")
+    for _ in range(4):                                          # keep the stream busy in front of the second plan / apply
+        filler = filler * 1.0001 + 0.5
+    rb = dn.densify(b, 0.0002, 0.005, 3.0, 20, normals=normals)
+    same = []                                                   # device-side comparisons queued right behind the apply launch
+    for k in DO.GROUPS:
+        pa, pb = getattr(a, ATTR[k]), getattr(b, ATTR[k])
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        same += [(pa.detach() == pb.detach()).all(), (sa["exp_avg"] == sb["exp_avg"]).all(), (sa["exp_avg_sq"] == sb["exp_avg_sq"]).all()]
+    for k in ("xyz_gradient_accum", "denom", "max_radii2D", "_deformation_accum", "_deformation_table"):
+        same.append((getattr(a, k) == getattr(b, k)).all())
+    assert ra == rb and ra[1] > 0 and ra[2] > 0
+    assert bool(torch.stack(same).all()), [bool(s) for s in same]
+    # ... and once more against a third model after a full synchronisation
+    c = model_from_state(st)
+    assert dn.densify(c, 0.0002, 0.005, 3.0, 20, normals=normals) == ra
+    torch.cuda.synchronize()
+    for k in DO.GROUPS:
+        assert torch.equal(getattr(a, ATTR[k]).detach(), getattr(c, ATTR[k]).detach()), k

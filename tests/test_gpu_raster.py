@@ -360,29 +360,32 @@ def test_blending_kernel_forms_agree(with_depth, monkeypatch):
             assert rel_l2(g[k], g0[k]) < 5e-6, (name, k, rel_l2(g[k], g0[k]))
 
 
-def test_capacity_mode_equals_the_blocking_exact_path(monkeypatch):
-    """For a training frame (`expect_backward`) rasterize_forward sizes the binning buffer from a predicted pair count once it has seen one
-    for (image size, Gaussian count) and runs the whole forward as ONE non-blocking C call (fdgs_raster_fwd_capacity: the kernels read the
-    true count on the device).  Same image, depth, radii and per-pixel bookkeeping bit for bit, same sorted lists and ranges, same gradients
-    as the blocking exact path -- which a frame without a backward (evaluation) always takes."""
+def test_capacity_paths_equal_the_blocking_exact_path(monkeypatch):
+    """Once a pair count has been seen for (image size, Gaussian count) rasterize_forward sizes the binning buffer from a predicted count and
+    queues the whole forward with ONE C call (fdgs_raster_fwd_capacity: the kernels read the true count on the device); the default mode
+    then verifies the count before it returns, the opt-in "capacity" mode does not.  Same image, depth, radii and per-pixel bookkeeping bit
+    for bit, same sorted lists and ranges, same gradients as the blocking exact path, training frame or evaluation frame."""
     dev = torch.device("cuda:0")
     R = _mod().rasterizer
     sc = raster_scene(30000, 640, 480, seed=21, scale_boost=1.5)
     rng = np.random.default_rng(5)
     wc = torch.tensor(rng.standard_normal((3, 480, 640)).astype(np.float32), device=dev)
     outs = {}
-    for mode in ("exact", "auto"):
+    for mode in ("exact", "auto", "capacity"):
         monkeypatch.setattr(R, "BINNING", mode)
-        if mode == "auto":
+        if mode != "exact":
             assert (dev.index, 640, 480, 30000) in R._seen    # the exact frame above fed the predictor
         t = {k: torch.tensor(sc[k], device=dev, requires_grad=True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
         color, radii, depth, st = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
                                                       t["rotations"], None, expect_backward=True)
         if mode == "auto":
-            # ... and an evaluation frame (no backward expected) of the same scene stays on the exact path whatever the predictor knows
-            _, _, _, st_eval = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
-                                                   t["rotations"], None)
-            assert st_eval.count.capacity is None and st_eval.capacity == st_eval.num_rendered
+            # the verified path: the count is known when the call returns, the buffer is laid out for the predicted capacity
+            assert st.count.R is not None and st.count.capacity is None and st.capacity >= st.count.R > 0 and st.capacity % 4096 == 0
+            # ... and an evaluation frame (no backward expected) takes the same verified path
+            c_eval, _, d_eval, st_eval = R.rasterize_forward(_settings(sc, dev, debug=False), t["means3D"], t["shs"], None, t["opacities"], t["scales"],
+                                                             t["rotations"], None)
+            assert st_eval.count.R == st.count.R and torch.equal(c_eval, color) and torch.equal(d_eval, depth)
+        elif mode == "capacity":
             assert st.count.capacity is not None and st.capacity >= st.num_rendered > 0 and st.capacity % 4096 == 0
         else:
             assert st.count.capacity is None and st.capacity == st.num_rendered
@@ -392,24 +395,71 @@ def test_capacity_mode_equals_the_blocking_exact_path(monkeypatch):
         outs[mode] = dict(color=color.clone(), radii=radii.clone(), depth=depth.clone(), n=n, gid=_binning(st, 0, dev)[:n], tile=_binning(st, 1, dev)[:n],
                           ranges=_img(st, 2, (((480 + 15) // 16) * ((640 + 15) // 16), 2), torch.int32, dev),
                           ncontrib=_img(st, 1, (480, 640), torch.int32, dev), grads={k: v.clone() for k, v in g.items() if v is not None})
-    a, b = outs["exact"], outs["auto"]
-    assert a["n"] == b["n"]
-    for k in ("color", "radii", "depth"):
-        assert torch.equal(a[k], b[k]), k
-    for k in ("gid", "tile", "ranges", "ncontrib"):
-        assert np.array_equal(a[k], b[k]), k
-    for k in a["grads"]:
-        assert rel_l2(b["grads"][k].cpu().numpy(), a["grads"][k].cpu().numpy()) < 5e-6, k
+    a = outs["exact"]
+    for mode in ("auto", "capacity"):
+        b = outs[mode]
+        assert a["n"] == b["n"]
+        for k in ("color", "radii", "depth"):
+            assert torch.equal(a[k], b[k]), (mode, k)
+        for k in ("gid", "tile", "ranges", "ncontrib"):
+            assert np.array_equal(a[k], b[k]), (mode, k)
+        for k in a["grads"]:
+            assert rel_l2(b["grads"][k].cpu().numpy(), a["grads"][k].cpu().numpy()) < 5e-6, (mode, k)
 
 
-def test_capacity_overflow_is_detected_and_the_capacity_grows(monkeypatch):
-    """A frame that lists more pairs than its binning buffer was sized for drops its FARTHEST pairs (never writes out of bounds), is reported
-    with a RuntimeWarning when its count arrives, counted in `capacity_overflows`, and the next frame's capacity covers it."""
+def test_capacity_overflow_in_the_default_mode_returns_the_exact_frame(monkeypatch):
+    """The default binning mode never returns an image that differs from the exact path: a frame that lists more pairs than its speculative
+    binning buffer holds is finished exactly (fdgs_bin_sort + fdgs_render_fwd on a buffer of the true size) BEFORE rasterize_forward returns
+    -- same image, depth, radii, lists, per-pixel bookkeeping and gradients as the blocking path -- and counted in `capacity_reruns`."""
+    dev = torch.device("cuda:0")
+    R = _mod().rasterizer
+    sc = raster_scene(20000, 416, 304, seed=22, scale_boost=2.0)
+    rng = np.random.default_rng(6)
+    wc = torch.tensor(rng.standard_normal((3, 304, 416)).astype(np.float32), device=dev)
+    t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    args = (t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
+    key = (dev.index, 416, 304, 20000)
+    tiles = ((304 + 15) // 16) * ((416 + 15) // 16)
+
+    def frame():
+        color, radii, depth, st = R.rasterize_forward(_settings(sc, dev, debug=False), *args, expect_backward=True)
+        g = R.rasterize_backward(st, wc)
+        torch.cuda.synchronize()
+        n = st.num_rendered
+        return dict(color=color.clone(), radii=radii.clone(), depth=depth.clone(), n=n, gid=_binning(st, 0, dev)[:n], tile=_binning(st, 1, dev)[:n],
+                    ranges=_img(st, 2, (tiles, 2), torch.int32, dev), ncontrib=_img(st, 1, (304, 416), torch.int32, dev),
+                    grads={k: v.clone() for k, v in g.items() if v is not None}), st
+
+    monkeypatch.setattr(R, "BINNING", "exact")
+    want, st0 = frame()
+    assert want["n"] > 40000
+    monkeypatch.setattr(R, "BINNING", "auto")
+    for too_low in (want["n"] // 4, 1):                                                              # a predictor that is far too low
+        R._seen[key] = [too_low, 20000]
+        before = R.capacity_reruns
+        got, st1 = frame()
+        assert R.capacity_reruns == before + 1 and R._seen[key][0] == want["n"]                      # detected, finished exactly, learnt
+        assert st1.capacity == want["n"] == got["n"] and st1.count.capacity is None
+        for k in ("color", "radii", "depth"):
+            assert torch.equal(want[k], got[k]), k
+        for k in ("gid", "tile", "ranges", "ncontrib"):
+            assert np.array_equal(want[k], got[k]), k
+        for k in want["grads"]:
+            assert rel_l2(got["grads"][k].cpu().numpy(), want["grads"][k].cpu().numpy()) < 5e-6, k
+    before = R.capacity_reruns
+    got, st2 = frame()                                                                               # the predictor has learnt: no re-run
+    assert R.capacity_reruns == before and st2.capacity >= want["n"] and torch.equal(got["color"], want["color"])
+
+
+def test_opt_in_capacity_mode_reports_an_overflow_and_grows(monkeypatch):
+    """BINNING = "capacity" (opt-in, never waits): a frame that lists more pairs than its binning buffer was sized for drops its FARTHEST
+    pairs (never writes out of bounds), is reported with a RuntimeWarning when its count arrives, counted in `capacity_overflows`, and the
+    next frame's capacity covers it."""
     import warnings
     dev = torch.device("cuda:0")
     R = _mod().rasterizer
     sc = raster_scene(20000, 416, 304, seed=22, scale_boost=2.0)
-    monkeypatch.setattr(R, "BINNING", "auto")
+    monkeypatch.setattr(R, "BINNING", "capacity")
     t = {k: torch.tensor(sc[k], device=dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     args = (t["means3D"], t["shs"], None, t["opacities"], t["scales"], t["rotations"], None)
     key = (dev.index, 416, 304, 20000)

@@ -28,6 +28,8 @@ class _FakeLib:
                 ctypes.cast(a[3], ctypes.POINTER(ctypes.c_uint32))[0] = 7
             elif name == "fdgs_raster_fwd_capacity":      # (the device would deliver the count later; the fake delivers it at once)
                 ctypes.cast(a[6], ctypes.POINTER(ctypes.c_uint32))[0] = 7
+            elif name == "fdgs_pair_count_wait":
+                a[2].value = ctypes.cast(a[1], ctypes.POINTER(ctypes.c_uint32))[0]
             elif name == "fdgs_deform_bwd_live_tiles":
                 for i in range(4):
                     a[3][i] = 1
