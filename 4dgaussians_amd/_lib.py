@@ -85,6 +85,12 @@ class GaussiansOut(Structure):
                 ("max_radii2D", c_void_p), ("deformation_accum", c_void_p)]
 
 
+class RowArray(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("width", c_int)]
+
+
+MAX_ROW_ARRAYS = 8
+
 # every symbol include/fdgs.h declares: (restype, argtypes)
 SYMBOLS = {
     "fdgs_last_error": (c_char_p, []),
@@ -128,6 +134,7 @@ SYMBOLS = {
     "fdgs_densify_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_float, c_float, c_float, c_float, c_float, c_void_p, POINTER(c_uint32)]),
     "fdgs_densify_apply": (c_int, [c_void_p, POINTER(GaussiansIn), POINTER(GaussiansOut), c_void_p, c_void_p]),
+    "fdgs_permute_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, POINTER(RowArray), c_int]),
 }
 
 ABI_VERSION = 6       # what this Python host was written against (include/fdgs.h); checked when the library is loaded

@@ -116,6 +116,8 @@ struct DeformDev {
     int Npad;
     int head_slot[FDGS_NUM_HEADS];
     const float* packed;            // form 16: W0 / W1 as operand streams (pack_weights16_kernel)
+    const float* feat;              // weight-stationary form: the HexPlane features [Npad][F] (deform_gather_kernel)
+    unsigned head_mask;             // weight-stationary form: bit hd = head hd is on (a scalar the lanes can test with their own head index)
     int skew;                       // form 16: start delay (s_memtime ticks) of the second half of the grid (FDGS_D16_SKEW)
 };
 
@@ -721,6 +723,7 @@ __global__ void __launch_bounds__(256, 1) deform_fwd_kernel(DeformDev d) {
 }
 
 #include "deform_fwd16.h"
+#include "deform_fwd_ws.h"
 
 // ------------------------------------------------------------------------------------------------ backward: prep
 // Per Gaussian: activation Jacobians -> packed pre-activation output gradients G[n][64]; direct (identity) paths.
@@ -2660,9 +2663,25 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         // which form of the forward kernel: 16 (default where it applies: two waves per SIMD; in the frame, where the gather starts on cold
         // caches behind the previous frame's backward, it measured 5 - 7 % faster than the 32-form on every workload, profiles/r04_d1_forms.txt)
         // | 32 (also what runs when C*L is not a multiple of 16 or the caller hands over no pack scratch)
-        const bool form16 = g_tune.d1_form != 32 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
+        // which form of the forward kernel: 8 (default where it applies: the weight-stationary form of deform_fwd_ws.h -- net_width 64 / 128,
+        // C*L a multiple of 16; the gather runs as a kernel of its own in front of it) | 16 (two waves per SIMD on packed operand streams)
+        // | 32 (also what runs when C*L is not a multiple of 16 or the caller hands over no scratch)
+        const bool formws = g_tune.d1_form == 8 && (p->W == 64 || p->W == 128) && p->C % 4 == 0 && d.F % 16 == 0 && (out->saved || out->packed);
+        const bool form16 = !formws && g_tune.d1_form != 32 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         d.packed = reinterpret_cast<const float*>(out->packed);
+        d.feat = nullptr;
+        d.head_mask = 0u;
+        for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) d.head_mask |= p->head_on[hd] ? 1u << hd : 0u;
         d.skew = 600;       // (s_memtime ticks; sweep 0 .. 24 k in profiles/r04_d1_forms.txt)
+        if (formws) {
+            // features: into the saved activations when the backward will want them, into the scratch otherwise
+            float* feat = d.sv_feat ? d.sv_feat : reinterpret_cast<float*>(out->packed);
+            GatherArgs ga{};
+            ga.p = *p; ga.sc = d.sc; ga.F = d.F; ga.Npad = d.Npad; ga.feat = feat;
+            d.feat = feat;
+            FDGS_TIMED("deform_gather", stream);
+            hipLaunchKernelGGL(deform_gather_kernel, dim3(cdiv((long long)d.Npad * (p->C / 4), 256), p->L), dim3(256), 0, stream, ga);
+        }
         if (form16) {
             FDGS_TIMED("pack_weights", stream);
             PackArgs pa{};
@@ -2671,11 +2690,18 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
             const int n4 = (d.F * p->W + FDGS_NUM_HEADS * p->W * p->W) / 4;
             hipLaunchKernelGGL(pack_weights16_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, pa);
         }
-        const int want = g_tune.d1_wgs >= 0 ? g_tune.d1_wgs : (form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
-        const int wg_tiles = form16 ? d.ntiles / 2 : d.ntiles / 4;           // (form 16: four 16-Gaussian tiles per workgroup)
-        const int wgs = want > 0 && want < wg_tiles ? want : wg_tiles;
+        int wgs;
+        if (formws) {
+            const int per_cu = p->W == 128 ? 1 : 2, nt16 = d.Npad / 16;
+            const int want = g_tune.d1_wgs > 0 ? g_tune.d1_wgs : per_cu * cus;
+            wgs = want < nt16 ? want : nt16;
+        } else {
+            const int want = g_tune.d1_wgs >= 0 ? g_tune.d1_wgs : (form16 ? 2 * cus : cus);     // 0: one workgroup per four tiles (not persistent)
+            const int wg_tiles = form16 ? d.ntiles / 2 : d.ntiles / 4;           // (form 16: four 16-Gaussian tiles per workgroup)
+            wgs = want > 0 && want < wg_tiles ? want : wg_tiles;
+        }
         d.prof = nullptr;
-#ifdef FDGS_PROFILE_D1
+#if defined(FDGS_PROFILE_D1) || defined(FDGS_PROFILE_WS)
         static unsigned long long* prof_dev = nullptr;
         if (!prof_dev) { (void)hipMalloc(&prof_dev, 16 * sizeof(unsigned long long)); }
         (void)hipMemsetAsync(prof_dev, 0, 16 * sizeof(unsigned long long), stream);
@@ -2683,8 +2709,24 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
 #endif
         {
             FDGS_TIMED("deform_fwd", stream);       // (the forward kernel alone; the operand-stream copy above is timed as "pack_weights")
-            rc = form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
+            rc = formws ? dispatch_wf<FwdWsLauncher>(p->W, d.F, stream, wgs, d)
+               : form16 ? dispatch_wf<Fwd16Launcher>(p->W, d.F, stream, wgs, d) : dispatch_wf<FwdLauncher>(p->W, d.F, stream, wgs, d);
         }
+#ifdef FDGS_PROFILE_WS
+        {
+            static int reports = 0;
+            if (reports++ == 5) {
+                unsigned long long hb[16];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(hb, prof_dev, sizeof(hb), hipMemcpyDeviceToHost);
+                const char* names[7] = {"(loop top)", "feature park + request", "barrier", "copy-out + hmask", "heads", "epilogue", "trunk of the next tile"};
+                double tot = 0;
+                for (int i = 0; i < 7; i++) tot += (double)hb[i];
+                fprintf(stderr, "[D1-ws profile] %llu waves, s_memtime ticks per wave:\n", hb[8]);
+                for (int i = 0; i < 7; i++) fprintf(stderr, "  %-28s %12.0f  (%.1f %%)\n", names[i], (double)hb[i] / (double)hb[8], 100.0 * hb[i] / tot);
+            }
+        }
+#endif
 #ifdef FDGS_PROFILE_D1
         {
             static int reports = 0;
@@ -2712,7 +2754,10 @@ extern "C" int fdgs_deform_pack_bytes(const fdgs_deform_params* p, size_t* bytes
     int rc = validate_deform(p);
     if (rc) return rc;
     FDGS_REQUIRE(bytes, "bytes is NULL");
-    *bytes = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W) * sizeof(float);
+    // the operand streams of the 16-Gaussian form, or -- weight-stationary form without saved activations -- the gathered features [Npad][C*L]
+    const size_t streams = ((size_t)p->C * p->L * p->W + (size_t)FDGS_NUM_HEADS * p->W * p->W) * sizeof(float);
+    const size_t feats = npad_of(p->N) * (size_t)p->C * p->L * sizeof(float);
+    *bytes = streams > feats ? streams : feats;
     return FDGS_OK;
 }
 

@@ -308,3 +308,57 @@ extern "C" int fdgs_densify_apply(void* stream_, const fdgs_gaussians_in* in, co
     FDGS_LAUNCH_CHECK("densify_apply", 0, stream);
     return FDGS_OK;
 }
+
+// ---- row permutation of per-Gaussian arrays (round 6: the library keeps the spatial order for itself) ------------------------------------
+// out[i] = in[perm[i]] (gather) or out[perm[i]] = in[i] (scatter) for up to FDGS_MAX_ROW_ARRAYS arrays of 4-byte elements that share the
+// row index, in ONE launch (62 floats per row for the six Gaussian parameters + the screen-space sink).  render() reads an unordered model's parameters through the cached Hilbert permutation of its positions and hands
+// the per-Gaussian gradients back through the inverse -- 2 x 236 bytes per Gaussian and direction, HBM-bound.
+namespace fdgs {
+struct PermuteArgs {
+    int N, narrays, total, scatter;
+    const int32_t* perm;
+    const uint32_t* src[FDGS_MAX_ROW_ARRAYS];
+    uint32_t* dst[FDGS_MAX_ROW_ARRAYS];
+    int width[FDGS_MAX_ROW_ARRAYS], first[FDGS_MAX_ROW_ARRAYS];
+};
+constexpr int PERM_ROWS = 64;      // rows per workgroup
+// Per array, the workgroup's 64 rows are one contiguous block on the SEQUENTIAL side (element t of the block = row t / w, column t % w):
+// that side is read / written fully coalesced, the permuted side in runs of one row's w elements.
+__global__ void __launch_bounds__(256) permute_rows_kernel(PermuteArgs a) {
+    __shared__ long long prm[PERM_ROWS];
+    const long long row0 = (long long)blockIdx.x * PERM_ROWS;
+    const int nrows = (int)(a.N - row0 < PERM_ROWS ? a.N - row0 : PERM_ROWS);
+    if (threadIdx.x < nrows) prm[threadIdx.x] = a.perm[row0 + threadIdx.x];
+    __syncthreads();
+    for (int k = 0; k < a.narrays; k++) {
+        const int w = a.width[k], total = nrows * w;
+        const uint32_t* __restrict__ src = a.src[k];
+        uint32_t* __restrict__ dst = a.dst[k];
+        for (int t = threadIdx.x; t < total; t += 256) {
+            const int r = t / w, c = t - r * w;
+            const long long seq = row0 * w + t, rnd = prm[r] * w + c;
+            if (a.scatter) dst[rnd] = src[seq]; else dst[seq] = src[rnd];
+        }
+    }
+}
+}  // namespace fdgs
+
+extern "C" int fdgs_permute_rows(void* stream_, int N, const int32_t* perm, int narrays, const fdgs_row_array* arrays, int scatter) {
+    FDGS_REQUIRE(N >= 0 && narrays >= 0 && narrays <= FDGS_MAX_ROW_ARRAYS, "bad sizes");
+    if (N == 0 || narrays == 0) return FDGS_OK;
+    FDGS_REQUIRE(perm && arrays, "NULL pointer");
+    PermuteArgs a{};
+    a.N = N; a.narrays = narrays; a.scatter = scatter ? 1 : 0; a.perm = perm;
+    int total = 0;
+    for (int k = 0; k < narrays; k++) {
+        FDGS_REQUIRE(arrays[k].src && arrays[k].dst && arrays[k].width > 0, "row array needs src, dst and a positive width");
+        a.src[k] = reinterpret_cast<const uint32_t*>(arrays[k].src); a.dst[k] = reinterpret_cast<uint32_t*>(arrays[k].dst);
+        a.width[k] = arrays[k].width; a.first[k] = total;
+        total += arrays[k].width;
+    }
+    a.total = total;
+    hipStream_t stream = (hipStream_t)stream_;
+    { FDGS_TIMED("permute_rows", stream); hipLaunchKernelGGL(permute_rows_kernel, dim3(cdiv(N, PERM_ROWS)), dim3(256), 0, stream, a); }
+    FDGS_LAUNCH_CHECK("permute_rows", 0, stream);
+    return FDGS_OK;
+}

@@ -297,11 +297,13 @@ def invalidate_caches(*tensors):
     if not tensors:
         _aabb_cache.clear()
         _order_cache.clear()
+        _perm_cache.clear()
         _fresh_streak.clear()
         return
     for t in tensors:
         _aabb_cache.pop(id(t), None)
         _order_cache.pop(id(t), None)
+        _perm_cache.pop(id(t), None)
 
 
 def _aabb_to_host(aabb):
@@ -313,6 +315,67 @@ def _aabb_to_host(aabb):
     vals = [float(x) for x in aabb.detach().reshape(-1).cpu().tolist()]
     _cache_put(_aabb_cache, aabb, key, vals)
     return vals
+
+
+# ---- the spatial order kept INSIDE the library (round 6) ---------------------------------------------------------------------------------
+# The order of the Gaussians is free in the reference, and the deformation kernels are ~2x faster on a set whose neighbours in memory are
+# neighbours in space.  fdgs.densify.* keeps the model itself in that order -- but a train loop that keeps the reference's own
+# GaussianModel.densify / prune (train.py:259-285) appends clones and children at the tail and its set is in no order at all.  For such a
+# model render() reads the parameters THROUGH a Hilbert permutation of the positions, cached per position-Parameter OBJECT (the reference's
+# densify / prune always create new Parameters, scene/gaussian_model.py:331-389; optimizer steps move the points in place and leave the
+# order as good as it was), and hands radii / visibility / every per-Gaussian gradient back through the inverse: one gather and one
+# scatter launch per frame (fdgs_permute_rows, 2 x 236 bytes per Gaussian each).
+_perm_cache = {}     # id(xyz) -> (weakref, (shape, data_ptr), int32 permutation)
+
+
+def implicit_permutation(xyz, aabb=None):
+    """The cached Hilbert permutation of `xyz` (new row i = old row perm[i]), computed once per tensor object and storage."""
+    key = (tuple(xyz.shape), xyz.data_ptr())
+    e = _cache_get(_perm_cache, xyz, key)
+    if e is not None:
+        return e[2]
+    from . import densify as _densify
+    with torch.no_grad():
+        if aabb is not None and aabb.device == xyz.device:
+            keys = _densify.hilbert_keys(xyz, aabb[1], aabb[0])          # aabb[0] = max, aabb[1] = min (scene/hexplane.py:19-20)
+        else:
+            keys = _densify.hilbert_keys(xyz)
+        perm = torch.argsort(keys, stable=True).to(torch.int32).contiguous()
+    _cache_put(_perm_cache, xyz, key, perm)
+    return perm
+
+
+def permute_rows(perm, tensors, scatter=False):
+    """[out[i] = t[perm[i]] for t in tensors] (scatter: out[perm[i]] = t[i]) for per-Gaussian arrays of 4-byte elements, one launch per
+    eight arrays (fdgs_permute_rows).  None entries stay None."""
+    L = _lib.lib()
+    outs = [None] * len(tensors)
+    todo = [(i, t if t.is_contiguous() else t.contiguous()) for i, t in enumerate(tensors) if t is not None]
+    n = perm.shape[0]
+    for c0 in range(0, len(todo), _lib.MAX_ROW_ARRAYS):
+        chunk = todo[c0:c0 + _lib.MAX_ROW_ARRAYS]
+        arr = (_lib.RowArray * len(chunk))()
+        for k, (i, t) in enumerate(chunk):
+            if t.element_size() != 4 or t.shape[0] != n:
+                raise ValueError("permute_rows: arrays of 4-byte elements with one row per Gaussian")
+            outs[i] = torch.empty_like(t)
+            arr[k].src, arr[k].dst, arr[k].width = t.data_ptr(), outs[i].data_ptr(), (t.numel() // n if n else 1)
+        check(L.fdgs_permute_rows(stream_ptr(), n, ptr(perm), len(chunk), arr, 1 if scatter else 0))
+    return outs
+
+
+class PermuteRows(torch.autograd.Function):
+    """The model's per-Gaussian arrays read through a permutation; the gradients go back through its inverse."""
+
+    @staticmethod
+    def forward(ctx, perm, *tensors):
+        ctx.perm = perm
+        ctx.set_materialize_grads(False)
+        return tuple(permute_rows(perm, [t.detach() for t in tensors]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None, *permute_rows(ctx.perm, list(grads), scatter=True))
 
 
 def spatial_order_hint(xyz):

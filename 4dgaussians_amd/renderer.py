@@ -28,6 +28,19 @@ EPILOGUE_ASSIGN = True     # False: the epilogue accumulates (+=) into a zero-fi
 EPILOGUE_TILE_FLAGS = None
 
 
+# The spatial order kept inside the library: a model whose rows are NOT spatial neighbours (the reference's own densify / prune appends at
+# the tail) is read through a cached Hilbert permutation of its positions (deformation.implicit_permutation); radii, visibility and the
+# per-Gaussian gradients come back in the model's own order.  FDGS_IMPLICIT_ORDER=0 switches it off (the A/B figure `random_order` of bench.py).
+IMPLICIT_ORDER = os.environ.get("FDGS_IMPLICIT_ORDER", "1") != "0"
+IMPLICIT_ORDER_MIN_N = 8192
+
+
+def _implicit_perm(pc, cfg, dn):
+    if IMPLICIT_ORDER and not cfg["ordered"] and pc._xyz.shape[0] >= IMPLICIT_ORDER_MIN_N and pc._xyz.dtype == torch.float32:
+        return _deformation.implicit_permutation(pc._xyz, dn.grid.aabb)
+    return None
+
+
 def _tile_flags():
     if EPILOGUE_TILE_FLAGS is not None:
         return int(EPILOGUE_TILE_FLAGS)
@@ -203,8 +216,14 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0, st
     cfg = dict(C=dn.grid.grid_config[0]["output_coordinate_dim"], L=len(dn.grid.grids), W=dn.W, head_on=_deformation._head_on(dn.args),
                activate=True, save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()), grad=torch.is_grad_enabled(),
                ordered=_deformation.spatial_order_hint(pc._xyz))
-    colors, radii, depths = _FusedRenderViewsFunction.apply(cfg, times, settings, len(cams), *sinks, means3D, pc._scaling, pc._rotation,
-                                                            pc._opacity, pc._features_dc, pc._features_rest, dn.grid.aabb, *planes, *mlp)
+    perm = _implicit_perm(pc, cfg, dn)
+    ins = (*sinks, means3D, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest)
+    if perm is not None:       # the set in Hilbert order for this step (gradients come back through the inverse)
+        cfg["ordered"] = True
+        ins = _deformation.PermuteRows.apply(perm, *ins) if cfg["grad"] else tuple(_deformation.permute_rows(perm, [t.detach() for t in ins]))
+    colors, radii, depths = _FusedRenderViewsFunction.apply(cfg, times, settings, len(cams), *ins, dn.grid.aabb, *planes, *mlp)
+    if perm is not None:
+        radii = torch.stack(_deformation.permute_rows(perm, [radii[v] for v in range(len(cams))], scatter=True))
     return [{"render": colors[v], "viewspace_points": sinks[v], "visibility_filter": radii[v] > 0, "radii": radii[v], "depth": depths[v]}
             for v in range(len(cams))]
 
@@ -280,18 +299,35 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                        head_on=_deformation._head_on(dn.args), activate=True,
                        save=bool(_deformation.SAVE_ACTIVATIONS and torch.is_grad_enabled()), grad=torch.is_grad_enabled(),
                        ordered=_deformation.spatial_order_hint(pc._xyz))
+            perm = _implicit_perm(pc, cfg, dn)
+            f_dc, f_rest = pc._features_dc, pc._features_rest
+            if perm is not None:       # the set in Hilbert order for this frame (gradients come back through the inverse)
+                cfg["ordered"] = True
+                if cfg["grad"]:
+                    means2D, means3D, scales, rotations, opacity, f_dc, f_rest = _deformation.PermuteRows.apply(
+                        perm, means2D, means3D, scales, rotations, opacity, f_dc, f_rest)
+                else:
+                    means3D, scales, rotations, opacity, f_dc, f_rest = _deformation.permute_rows(
+                        perm, [t.detach() for t in (means3D, scales, rotations, opacity, f_dc, f_rest)])
             if not cfg["grad"]:
                 # no graph will be recorded (render.py:57-70, evaluation): the two stages called directly -- autograd.Function.apply costs
                 # 0.05 ms per frame for its 46 inputs even when it has nothing to record
-                st = _deformation.forward_impl(cfg, frame_time, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
+                st = _deformation.forward_impl(cfg, frame_time, means3D, scales, rotations, opacity, f_dc, f_rest,
                                                None, dn.grid.aabb, (*planes, *mlp), False)
                 rendered_image, radii, depth, rstate = _rasterizer.rasterize_forward(raster_settings, st.o_xyz, st.o_sh, None, st.o_op, st.o_sc,
                                                                                      st.o_rot, None, expect_backward=False)
-                return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": rstate.visibility,
+                vis = rstate.visibility
+                if perm is not None:
+                    radii, = _deformation.permute_rows(perm, [radii], scatter=True)
+                    vis = radii > 0
+                return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": vis,
                         "radii": radii, "depth": depth}
             rendered_image, radii, depth, vis = _FusedRenderFunction.apply(
-                cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, pc._features_dc, pc._features_rest,
+                cfg, frame_time, raster_settings, means2D, means3D, scales, rotations, opacity, f_dc, f_rest,
                 dn.grid.aabb, *planes, *mlp)
+            if perm is not None:
+                radii, = _deformation.permute_rows(perm, [radii], scatter=True)
+                vis = radii > 0
             return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": vis,
                     "radii": radii, "depth": depth}
         elif fused:

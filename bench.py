@@ -403,19 +403,29 @@ def run(args, make_step=None):
             extras[other + "_scene"]["parity"] = rank0_leg(par, rank, other_leg)
         del pc_s, step_s
         torch.cuda.empty_cache()
-        # ---- the generator's (random) order of the same scene: no spatial locality, no contiguous dead tiles
+        # ---- the generator's (random) order of the same scene -- what an UNMODIFIED train loop (the reference's own densify / prune) keeps:
+        # by default render() reads such a model through its cached Hilbert permutation (renderer.IMPLICIT_ORDER); the second entry switches
+        # that off (no spatial locality, no contiguous dead tiles: the figure of rounds 2 - 5)
         if args.order != "random":
             pc_r = syn.SynthModel(N, dcfg, seed=6666, device=dev, scene=scene)
-            step_r = make_render_step(pc_r)
-            for i in range(3):
-                step_r(i)
-            rg, _ = timed_regions(step_r, 3, args.steps, 3, par, dev)
-            kr = kernel_times(step_r, max(args.steps // 2, 2))
-            dtr = sorted(rg)[1]
-            extras["random_order"] = {"frames_per_s": world * args.steps / dtr, "ms_per_step": dtr / args.steps * 1e3,
-                                      "what": "the same scene in the generator's order (SURVEY 8d), i.e. without fdgs.densify.spatial_reorder",
-                                      "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]}}
-            del pc_r, step_r
+            for name, implicit in (("random_order", True), ("random_order_implicit_permutation_off", False)):
+                fdgs.renderer.IMPLICIT_ORDER = implicit
+                try:
+                    step_r = make_render_step(pc_r)
+                    for i in range(3):
+                        step_r(i)
+                    rg, _ = timed_regions(step_r, 3, args.steps, 3, par, dev)
+                    kr = kernel_times(step_r, max(args.steps // 2, 2))
+                finally:
+                    fdgs.renderer.IMPLICIT_ORDER = True
+                dtr = sorted(rg)[1]
+                extras[name] = {"frames_per_s": world * args.steps / dtr, "ms_per_step": dtr / args.steps * 1e3,
+                                "what": ("the same scene in the generator's order (SURVEY 8d), no fdgs.densify.spatial_reorder call by anyone: render() reads the "
+                                         "model through the cached Hilbert permutation of its positions and returns radii / gradients in the model's order"
+                                         if implicit else "the same, with the implicit permutation switched off (FDGS_IMPLICIT_ORDER=0)"),
+                                "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kr.items(), key=lambda kv: -kv[1]["ms_per_step"])[:7]}}
+                del step_r
+            del pc_r
             torch.cuda.empty_cache()
         # ---- what keeping the order costs: spatial_reorder on the model WITH optimizer state (Adam moments permuted too), as the
         # densification hook runs it every `densification_interval` (100) iterations

@@ -436,6 +436,14 @@ int fdgs_densify_plan(void* stream, int mode, int N, const float* xyz_gradient_a
 int fdgs_densify_apply(void* stream, const fdgs_gaussians_in* in, const fdgs_gaussians_out* out, const void* scratch,
                        const float* split_samples_opt);
 
+/* ABI 6: row permutation of per-Gaussian arrays of 4-byte elements that share the row index, in one launch:
+ * dst[i] = src[perm[i]] (scatter = 0) or dst[perm[i]] = src[i] (scatter = 1), rows of `width` elements.  `perm` is a permutation of 0 .. N-1
+ * (int32, device).  The Python host reads an unordered model's parameters through the cached Hilbert permutation of its positions
+ * (fdgs.render) and hands the per-Gaussian gradients back through the inverse. */
+#define FDGS_MAX_ROW_ARRAYS 8
+typedef struct fdgs_row_array { const void* src; void* dst; int width; } fdgs_row_array;
+int fdgs_permute_rows(void* stream, int N, const int32_t* perm, int narrays, const fdgs_row_array* arrays, int scatter);
+
 #ifdef __cplusplus
 }
 #endif

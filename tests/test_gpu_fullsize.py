@@ -157,3 +157,46 @@ def test_spatial_reorder_leaves_the_frame_unchanged_and_permutes_the_gradients()
         if k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
             a = a[perm]
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 2e-4, k
+
+
+@pytest.mark.parametrize("views", [0, 2])
+def test_implicit_permutation_of_an_unordered_model_changes_nothing_the_caller_sees(views, monkeypatch):
+    """An UNMODIFIED train loop (the reference's own densify / prune) keeps its Gaussians in no order at all.  render() then reads the model
+    through a cached Hilbert permutation of its positions (renderer.IMPLICIT_ORDER, the default) -- and everything the caller sees is in
+    the MODEL'S order: same image, same radii / visibility, same per-Gaussian gradients and viewspace gradient row for row, same plane /
+    MLP gradients as with the permutation switched off; also through render_views and under torch.no_grad()."""
+    fd = importlib.import_module("4dgaussians_amd")
+    dev = torch.device("cuda:0")
+    N, W, H = 60_000, 640, 480
+    cams = [c.to(dev) for c in synthetic.orbit_cameras(W, H, n=160)[21:23]]
+    wimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
+    outs = {}
+    for implicit in (False, True):
+        monkeypatch.setattr(fd.renderer, "IMPLICIT_ORDER", implicit)
+        pc = synthetic.SynthModel(N, "dynerf_default", seed=77).to(dev)
+        with torch.no_grad():
+            pc._scaling.add_(0.5)
+        assert fd.deformation.spatial_order_hint(pc._xyz) is False           # the generator's order
+        pipe, bg = synthetic.PipelineParams(), torch.zeros(3, device=dev)
+        if views:
+            res = fd.render_views(cams[:views], pc, pipe, bg, stage="fine")
+            sum((r["render"] * wimg).sum() for r in res).backward()
+        else:
+            res = [fd.render(cams[0], pc, pipe, bg, stage="fine")]
+            (res[0]["render"] * wimg).sum().backward()
+        with torch.no_grad():
+            plain = fd.render(cams[0], pc, pipe, bg, stage="fine")
+        outs[implicit] = (res, {k: v.grad for k, v in pc.named_parameters() if v.grad is not None}, plain)
+        assert (id(pc._xyz) in fd.deformation._perm_cache) == implicit
+    (ra, ga, pa), (rb, gb, pb) = outs[False], outs[True]
+    for a, b in zip(ra + [pa], rb + [pb]):
+        d = (a["render"] - b["render"]).abs()
+        assert float(d.mean()) < 1e-7 and float(torch.quantile(d.flatten()[::7], 0.9999)) < 1e-5     # (equal-depth ties may reorder)
+        assert torch.equal(a["radii"], b["radii"]) and torch.equal(a["visibility_filter"], b["visibility_filter"])
+        assert a["radii"].dtype == b["radii"].dtype and a["visibility_filter"].dtype == torch.bool
+    for a, b in zip(ra, rb):
+        ga2, gb2 = a["viewspace_points"].grad, b["viewspace_points"].grad
+        assert rel_l2(gb2.cpu().numpy(), ga2.cpu().numpy()) < 2e-4
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert ga[k].shape == gb[k].shape and rel_l2(gb[k].cpu().numpy(), ga[k].cpu().numpy()) < 2e-4, k
