@@ -152,33 +152,38 @@ __global__ void __launch_bounds__(256, RT == 2 ? 1 : 2) deform_mlp_ws_kernel(Def
     // flight" with K = the stores issued behind the loads (SAVE: >= 12 per iteration) does not wait for those stores, while vmcnt(0) does
     // (measured: 1.8 k of a tile's 20 k ticks).  hipcc derives K from the paths that reach the parking: the loop is entered with NOTHING in
     // flight (the prologue parks what it loads), so the only path with loads in flight is the back edge with its stores behind them.
+    // Work item of the epilogue = (four-float chunk c, Gaussian nn), FIXED per thread: every wave takes one of the four k <= 4 heads (16
+    // lanes) and three of the twelve SH row chunks (48 lanes) -- the same mix of stores for every wave (chunk-major with wave 0 taking all
+    // four small heads had the other three waiting at the barrier).  The item's four inputs come from one of six arrays with its own row
+    // stride: which array, which elements and the stride are worked out ONCE per thread; per tile an address is base + row * stride (this
+    // wave is alone on its SIMD: every VALU instruction of the tile loop that does not sit in the shadow of an MFMA costs its four cycles in
+    // the open, and the per-tile version of this address arithmetic was 1.5 k of a tile's 20 k ticks).
+    const int my_c = ((tid >> 4) & 3) == 0 ? (tid >> 6) : 4 + 3 * (tid >> 6) + ((tid >> 4) & 3) - 1, my_nn = tid & 15;
+    const float* in_base[4];
+    int in_stride[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = 4 * (my_c - 4) + i, i3 = i < 3 ? i : 2;
+        if (my_c >= 4) { in_base[i] = m < 3 ? p.shs_dc + m : p.shs_rest + (m - 3); in_stride[i] = m < 3 ? p.shs_dc_stride : p.shs_rest_stride; }
+        else if (my_c == FDGS_HEAD_ROT) { in_base[i] = p.rotations + i; in_stride[i] = 4; }
+        else if (my_c == FDGS_HEAD_OPACITY) { in_base[i] = p.opacity; in_stride[i] = 1; }
+        else if (my_c == FDGS_HEAD_SCALE) { in_base[i] = p.scales + i3; in_stride[i] = 3; }
+        else { in_base[i] = p.xyz + i3; in_stride[i] = 3; }
+    }
     auto request = [&](int ftile, int itile, float4* fdst, float4& idst) {
 #pragma unroll
         for (int e = 0; e < FLD; e++) {
             const int i4 = tid + e * NT;
             if (i4 < 16 * (F / 4) && ftile < ntiles) fdst[e] = reinterpret_cast<const float4*>(d.feat + (size_t)ftile * 16 * F)[i4];
         }
-        // the item's four inputs: ONE address computation (selects, no branches) and four unconditional dword loads straight into the
-        // destination -- loads inside an if / else chain are merged through copies, and a copy of a loaded value is a wait where it stands
-        // (rows beyond N load duplicates nobody uses)
-        const int c = tid >> 4, nn = tid & 15;
-        long long g_raw = (long long)(itile < ntiles ? itile : ntiles - 1) * 16 + nn;
-        if (g_raw >= p.N) g_raw = p.N - 1;
-        const size_t g = (size_t)g_raw;
-        const float* dc = p.shs_dc + (size_t)p.shs_dc_stride * g;
-        const float* rest = p.shs_rest + (size_t)p.shs_rest_stride * g;
-        const float* a4[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int m = 4 * (c - 4) + i, i3 = i < 3 ? i : 2;
-            const float* sh = m < 3 ? dc + (m < 0 ? 0 : m) : rest + (m - 3);
-            const float* sm = c == FDGS_HEAD_ROT ? p.rotations + 4 * g + i : c == FDGS_HEAD_OPACITY ? p.opacity + g
-                            : c == FDGS_HEAD_SCALE ? p.scales + 3 * g + i3 : p.xyz + 3 * g + i3;
-            a4[i] = c >= 4 ? sh : sm;
-        }
-        idst.x = *a4[0]; idst.y = *a4[1]; idst.z = *a4[2]; idst.w = *a4[3];
+        // four unconditional dword loads straight into the destination -- loads inside an if / else chain are merged through copies, and a
+        // copy of a loaded value is a wait where it stands (rows beyond N load duplicates nobody uses)
+        int g = (itile < ntiles ? itile : ntiles - 1) * 16 + my_nn;
+        g = g < p.N ? g : p.N - 1;
+        idst.x = in_base[0][(size_t)g * in_stride[0]]; idst.y = in_base[1][(size_t)g * in_stride[1]];
+        idst.z = in_base[2][(size_t)g * in_stride[2]]; idst.w = in_base[3][(size_t)g * in_stride[3]];
     };
-    auto park = [&](const float4* fsrc, const float4& isrc, float* fimg, float* iimg) {
+    auto park = [&](const float4* fsrc, const float4& isrc, float* fimg, float* iimg) {      // (the inputs sit in the slot of their thread)
 #pragma unroll
         for (int e = 0; e < FLD; e++) {
             const int i4 = tid + e * NT;
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(256, RT == 2 ? 1 : 2) deform_mlp_ws_kernel(Def
             const float4 b = *reinterpret_cast<const float4*>(&b2l[4 * c]);
             o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
         }
-        const float4 in = *reinterpret_cast<const float4*>(iimg + 4 * item);
+        const float4 in = *reinterpret_cast<const float4*>(iimg + 4 * tid);      // (requested and parked by this very thread)
         const float v0 = in.x + o.x, v1 = in.y + o.y, v2 = in.z + o.z, v3 = in.w + o.w;
         if (c >= 4) {
             *reinterpret_cast<float4*>(d.out.shs + 48 * g + 4 * (c - 4)) = make_float4(v0, v1, v2, v3);
@@ -412,12 +417,12 @@ __global__ void __launch_bounds__(256, RT == 2 ? 1 : 2) deform_mlp_ws_kernel(Def
         if (!trunk_done && tile + G < ntiles) trunk(fl[it ^ 1], xl[it ^ 1], hml[SAVE ? (it ^ 1) : 0]);
         WS_TICK(4);
         // ---- epilogue of the PREVIOUS tile (its partial sums and inputs were complete at the barrier above)
-        if (prev >= 0) epilogue(prev, it ^ 1, tid, inl[it ^ 1]);
+        if (prev >= 0) epilogue(prev, it ^ 1, (my_c << 4) | my_nn, inl[it ^ 1]);
         prev = tile;
         WS_TICK(5);
     }
     __syncthreads();      // the last tile's epilogue (its inputs were parked at the top of its iteration)
-    if (prev >= 0) epilogue(prev, it ^ 1, tid, inl[it ^ 1]);
+    if (prev >= 0) epilogue(prev, it ^ 1, (my_c << 4) | my_nn, inl[it ^ 1]);
 #ifdef FDGS_PROFILE_WS
     if (d.prof && lane == 0) {
         for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], pacc[i]);
