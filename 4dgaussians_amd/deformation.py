@@ -299,6 +299,7 @@ def invalidate_caches(*tensors):
         _order_cache.clear()
         _perm_cache.clear()
         _fresh_streak.clear()
+        _net_cache.clear()
         return
     for t in tensors:
         _aabb_cache.pop(id(t), None)
@@ -419,7 +420,10 @@ class _FwdState:
 
 
 _pack_scratch = {}
-_net_cache = {}       # "k" -> (key, planes, mlp): the last network's normalised tensor lists (forward_impl)
+_net_cache = {}       # (ids + storages of a network's 40 tensors) -> (planes, mlp): normalised tensor lists (forward_impl); a few networks (code
+                      # that alternates between models -- A/B legs, merge_many_4dgs.py -- must not thrash); the entries are detached views, i.e.
+                      # they keep the storages of at most _NET_CACHE_MAX networks alive (invalidate_caches() drops them)
+_NET_CACHE_MAX = 4
 
 
 def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_tensor, aabb, rest, want_backward):
@@ -438,17 +442,17 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
     # the network's 40 tensors: normalised (float32, planes channels-last) once per set of (tensor objects, storages) -- the optimizer
     # steps them in place, so on every frame but the first this is 80 id() / data_ptr() calls instead of ~120 tensor ops
     nkey = tuple(map(id, rest)) + tuple(t.data_ptr() for t in rest)
-    e = _net_cache.get("k")
-    if e is not None and e[0] == nkey:
-        planes, mlp = e[1], e[2]
+    e = _net_cache.get(nkey)
+    if e is not None:
+        planes, mlp = e
     else:
         planes = [_cl(p.detach()) for p in planes_in]
         mlp = [c(m) for m in mlp_in]
         # (only cached when nothing had to be converted: a converted copy would go stale under an in-place optimizer step)
         if all(a.data_ptr() == b.data_ptr() for a, b in zip(planes + mlp, rest)):
-            _net_cache["k"] = (nkey, planes, mlp)
-        else:
-            _net_cache.pop("k", None)
+            while len(_net_cache) >= _NET_CACHE_MAX:
+                del _net_cache[next(iter(_net_cache))]
+            _net_cache[nkey] = (planes, mlp)
     N = xyz_.shape[0]
     st = _FwdState()
     st.keep = []
@@ -466,20 +470,19 @@ def forward_impl(cfg, t_scalar, xyz, scales, rotations, opacity, sh_a, sh_b, t_t
         saved = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     out.saved = ptr(saved)
     st.saved_act = saved
-    # scratch for the operand-stream copy of W0 / W1 that the 16-Gaussians-per-wave form of the forward kernel reads (the default form; the
-    # library re-packs the weights into it in front of every forward; without it -- or with the tuning knob d1_form = 32 -- the library runs
-    # the 32-Gaussian form).  One persistent buffer per (device, stream, size): forwards on one stream are ordered, forwards on
+    # scratch of the forward kernel: the gathered HexPlane features of the weight-stationary form when nothing is saved for a backward (the
+    # default form), or the operand-stream copy of W0 / W1 of the 16-Gaussians-per-wave form (d1_form = 16; without a scratch the library
+    # falls back to the 32-Gaussian form).  One persistent buffer per (device, stream, size): forwards on one stream are ordered, forwards on
     # different streams must not share it.
-    if True:
-        nbytes = _lib.c_size_t()
-        check(L.fdgs_deform_pack_bytes(p, nbytes))
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, nbytes.value)
-        packed = _pack_scratch.get(key)
-        if packed is None:
-            if len(_pack_scratch) > 8:
-                _pack_scratch.clear()
-            packed = _pack_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        out.packed = ptr(packed)
+    nbytes = _lib.c_size_t()
+    check(L.fdgs_deform_pack_bytes(p, nbytes))
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, nbytes.value)
+    packed = _pack_scratch.get(key)
+    if packed is None:
+        if len(_pack_scratch) > 8:
+            _pack_scratch.clear()
+        packed = _pack_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    out.packed = ptr(packed)
     check(L.fdgs_deform_fwd(stream_ptr(), p, out))
     st.cfg, st.p = cfg, p
     st.shapes = dict(scales=scales.shape, rot=rotations.shape, op=opacity.shape, sh_a=sh_a.shape, sh_b=None if sh_b is None else sh_b.shape)

@@ -29,7 +29,10 @@ def init_from_env(backend=None, timeout_s=None):
                                "the frame-parallel path runs one process per GPU and never shares a device")
         torch.cuda.set_device(device)
         if world > 1:
-            pin_host_thread(device, local, world)
+            # ranks on THIS node (torchrun exports LOCAL_WORLD_SIZE; otherwise the GPUs visible here): the global world size would give a
+            # multi-node job slices for ranks that live elsewhere and pack the local ones into the first 1 / nnodes of the cores
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or min(world, n_vis)
+            pin_host_thread(device, local, max(local_world, local + 1))
     if world > 1 and not dist.is_initialized():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -396,7 +396,7 @@ def run(args, make_step=None):
                 _, ref_s = cpu_baseline(fdgs, syn, pc_s, cam_p, target, dcfg, 1, deformed=hip_deformed(fdgs, pc_s, cam_p))
                 prm_s = [p_ for p_ in pc_s.parameters() if p_.requires_grad]
                 full = parity_vs_oracle(fdgs, pc_s, cam_p, pipe, bg, prm_s, ref_s)
-                keep = ("deformation_max_abs_vs_oracle", "image_psnr_dB", "n_pixels_over_1e-4", "n_pixels", "radii_mismatch_frac", "grad_rel_l2_vs_float64_oracle",
+                keep = ("vs_reference_f32_modules_raw", "deformation_max_abs_vs_oracle", "image_psnr_dB", "n_pixels_over_1e-4", "n_pixels", "radii_mismatch_frac", "grad_rel_l2_vs_float64_oracle",
                         "grad_rel_l2_vs_float64_oracle_kink_rows_attributed", "kink_rows", "n_kink_rows", "max_kink_rows", "unexplained_rows",
                         "n_unexplained_rows", "attribution_windows", "grad_ok", "grad_failures", "viewspace_rel_l2")
                 return {k: full[k] for k in keep}
@@ -744,6 +744,20 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
     worst_tensor = max(((k, rel(impl[k], v)) for k, v in ref["grads64"].items()
                         if v is not None and float(np.abs(v).max()) > 0), key=lambda kv: kv[1])
     radii = res["radii"].cpu().numpy()
+    # the apples-to-apples figure for north_star's 1e-3: the same HIP gradients against the REFERENCE'S OWN float32 modules (render() +
+    # deform_network as torch ops on this device, over the same HIP rasterizer), raw -- no attribution (oracle/ref_f32.py)
+    ref32 = None
+    try:
+        from oracle import ref_f32
+        if ref_f32.available():
+            img32, radii32, g32, vs32 = ref_f32.reference_f32_frame(pc, pc._deformation.args, cam, pipe, bg, torch.tensor(ref["dc"], device=img.device))
+            ref32 = ref_f32.compare_raw(pc, g32, img32, im)
+            ref32["viewspace_rel_l2"] = float(f"{rel(res['viewspace_points'].grad.cpu().numpy(), vs32):.3e}")
+            ref32["radii_mismatch_frac"] = float((radii != radii32).mean())
+            ref32["what"] = ("HIP render() vs the reference's own render() + deform_network (float32 torch ops on this device, byte-compiled from "
+                             "/root/reference into oracle/_ref) over the same HIP rasterizer: raw group-wise relative L2, no kink attribution")
+    except Exception as e:      # (the comparator is optional infrastructure: its failure must not take the bench line down)
+        ref32 = {"error": f"{type(e).__name__}: {e}"}
     hd = hip_deformed(fdgs, pc, cam)
     n_ = hd[0].shape[0]
     stage_a = {k: float(f"{float((a.reshape(n_, -1) - b.reshape(n_, -1)).abs().max()):.3e}")
@@ -769,6 +783,7 @@ def parity_vs_oracle(fdgs, pc, cam, pipe, bg, params, ref):
             "grad_ok": att["ok"], "grad_failures": att["failures"],
             # for information: the same HIP gradients against the oracle's own float32 autograd (which has the same kinks as any float32 evaluation)
             "grad_rel_l2_vs_float32_oracle_info": {k: float(f"{v:.3e}") for k, v in grad_rel.items()},
+            "vs_reference_f32_modules_raw": ref32,
             "viewspace_rel_l2": float(f"{rel(res['viewspace_points'].grad.cpu().numpy(), ref['means2D']):.3e}"),
             "worst_single_tensor": {"name": worst_tensor[0], "rel_l2": float(f"{worst_tensor[1]:.3e}")},
             "tolerance": {"image_psnr_dB": ">= 80 (our reading of north_star's '1e-4 PSNR': mean squared error <= 1e-8; isolated alpha >= 1/255 "

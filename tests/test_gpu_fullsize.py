@@ -104,6 +104,23 @@ def test_render_fwd_bwd_parity_at_baseline_size(name, with_depth, order="hilbert
     print("   worst tensors (raw): " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
     assert rep["ok"], rep["failures"]
     assert vs <= 1e-3, vs
+    # ---- the apples-to-apples figure for north_star's 1e-3 (round 6): the same HIP gradients against the REFERENCE'S OWN float32 modules --
+    # its render() + deform_network as torch ops on this device, over the same HIP rasterizer -- RAW, no attribution (oracle/ref_f32.py).
+    # Two float32 evaluations of the same function take near-zero ReLU / texel-cell decisions apart from each other just as a float32 and a
+    # float64 one do, so a scene with such rows (shell: five of 300 000) shows them here too; the bound asserted is what the reference's own
+    # float32 modules are measured to differ from the float64 oracle by on the same scenes (tools/parity_windows.py), 5e-3, and the figure is
+    # printed for the record (bench.py carries it in its parity block: `vs_reference_f32_modules_raw`).
+    from oracle import ref_f32
+    if ref_f32.available() and not with_depth:
+        dcol = torch.tensor(dc, device=dev)
+        img32, radii32, g32, vs32 = ref_f32.reference_f32_frame(pc, pc._deformation.args, cam.to(dev), synthetic.PipelineParams(), torch.zeros(3, device=dev), dcol)
+        raw = ref_f32.compare_raw(pc, g32, img32, im)
+        vs_raw = rel_l2(res["viewspace_points"].grad.cpu().numpy(), vs32)
+        print(f"   RAW vs the reference's own float32 modules on this device: " + ", ".join(f"{k}={v:.2e}" for k, v in raw["groups"].items())
+              + f", viewspace={vs_raw:.2e}; image mean abs {raw['image_mean_abs']:.2e}; worst tensor {raw['worst_single_tensor']}")
+        assert raw["image_mean_abs"] < 2e-6 and float((radii != radii32).mean()) < 2e-4
+        assert max(raw["groups"].values()) <= 5e-3 and vs_raw <= 1e-3, raw
+        assert sum(v <= 1e-3 for v in raw["groups"].values()) >= len(raw["groups"]) - 2, raw      # (north_star's bound itself: on all but the kink-carrying groups)
     # parameters of disabled heads / the unused time net get no gradient on either side
     for k, v in gref.items():
         if not k.startswith("__") and (v is None or float(np.abs(v).max()) == 0.0):
