@@ -54,7 +54,7 @@ constexpr int WAVE = 64;
 // only through fdgs_tuning_set() -- no C-ABI call reads the environment.  Everything else that used to be an FDGS_* variable is a constant
 // at its point of use (the tuned value; the sweeps are in profiles/r01b_tuning_sweep.txt).  Documented in INTEGRATION.md.
 struct Tuning {
-    int d1_form;     // FDGS_D1_FORM     8 (default: the weight-stationary form, deform_fwd_ws.h, where it applies) | 16 (deform_fwd16_kernel) | 32 (deform_fwd_kernel)
+    int d1_form;     // FDGS_D1_FORM     0 (default: by shape, 8 at net_width 128 with up to two HexPlane levels, else 16) | 8 ( the weight-stationary form, deform_fwd_ws.h, where it applies) | 16 (deform_fwd16_kernel) | 32 (deform_fwd_kernel)
     int d1_wgs;      // FDGS_D1_WGS      workgroups of the forward kernel; -1 = two (form 16) / one (form 32) per CU, 0 = one per four tiles
     int d1_split;    // FDGS_D1_SPLIT    1 = the leftover tiles of the persistent loop are split by head over the waves
     int skip_dead;   // FDGS_SKIP_DEAD   1 = the deformation backward skips tiles without a gradient row (modes 0 / 2 of packed_rows_ready)

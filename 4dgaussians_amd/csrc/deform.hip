@@ -2663,11 +2663,14 @@ extern "C" int fdgs_deform_fwd(void* stream_, const fdgs_deform_params* p, const
         // which form of the forward kernel: 16 (default where it applies: two waves per SIMD; in the frame, where the gather starts on cold
         // caches behind the previous frame's backward, it measured 5 - 7 % faster than the 32-form on every workload, profiles/r04_d1_forms.txt)
         // | 32 (also what runs when C*L is not a multiple of 16 or the caller hands over no pack scratch)
-        // which form of the forward kernel: 8 (default where it applies: the weight-stationary form of deform_fwd_ws.h -- net_width 64 / 128,
+        // which form of the forward kernel: 0 (default) = by shape -- form 8 at net_width 128 with up to two HexPlane levels, form 16 otherwise (config 2's 0.8-ms frame is paced by the host: one more launch costs more than the kernel gains): the gather of form 8 is a
+        // kernel of its own whose time grows with the levels while form 16 hides it under its products (measured, profiles/r06_d1_forms_by_config.txt:
+        // config 3, three levels: 0.432 + 0.062 ms against 0.462 + 0.006; configs 4 / 5, two levels: 0.570 + 0.039 against 0.633, 3.70 + 0.21 against 4.11);
+        // 8 (forced where it applies: the weight-stationary form of deform_fwd_ws.h -- net_width 64 / 128,
         // C*L a multiple of 16; the gather runs as a kernel of its own in front of it) | 16 (two waves per SIMD on packed operand streams)
         // | 32 (also what runs when C*L is not a multiple of 16 or the caller hands over no scratch)
-        const bool formws = g_tune.d1_form == 8 && (p->W == 64 || p->W == 128) && p->C % 4 == 0 && d.F % 16 == 0 && (out->saved || out->packed);
-        const bool form16 = !formws && g_tune.d1_form != 32 && p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
+        const bool formws = (g_tune.d1_form == 8 || (g_tune.d1_form == 0 && p->L <= 2 && p->W == 128)) && (p->W == 64 || (p->W == 128 && d.F <= 48)) && p->C % 4 == 0 && d.F % 16 == 0 && (out->saved || out->packed);   // (net_width 128 with C*L > 48: W0 no longer fits the registers next to the five W1 -- and this kernel must not spill)
+        const bool form16 = !formws && g_tune.d1_form != 32 &&   /* (d1_form 0 = by shape: form 8 up to two HexPlane levels, form 16 above) */ p->C % 16 == 0 && d.F % 16 == 0 && out->packed != nullptr;
         d.packed = reinterpret_cast<const float*>(out->packed);
         d.feat = nullptr;
         d.head_mask = 0u;

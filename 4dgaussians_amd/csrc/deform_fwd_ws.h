@@ -432,9 +432,9 @@ __global__ void __launch_bounds__(256, RT == 2 ? 1 : 2) deform_mlp_ws_kernel(Def
 }
 
 template <int WT, int FCH>
-struct FwdWsLauncher {      // (the caller only selects this form when C*L % 16 == 0 and W is 64 or 128)
+struct FwdWsLauncher {      // (the caller only selects this form when C*L % 16 == 0 and W is 64, or 128 with C*L <= 48)
     static void go(hipStream_t s, int blocks, const DeformDev& d) {
-        if constexpr ((FCH % 2) == 0 && (WT == 2 || WT == 4)) {
+        if constexpr ((FCH % 2) == 0 && (WT == 2 || (WT == 4 && FCH <= 6))) {
             constexpr int RT = WT / 2;
             const bool save = d.sv_h1 != nullptr, allh = d.head_mask == 31u;
             if (save && allh) hipLaunchKernelGGL((deform_mlp_ws_kernel<RT, FCH / 2, true, true>), dim3(blocks), dim3(256), 0, s, d);

@@ -305,6 +305,7 @@ def run(args, make_step=None):
     valu_flops = {"render_fwd": blend_pairs * BLEND_FLOP_FWD, "render_bwd": blend_pairs * BLEND_FLOP_BWD}
     hbm_bytes = {"preprocess_fwd": stage_bytes["preprocess_fwd"], "preprocess_bwd": stage_bytes["preprocess_bwd"],
                  "deform_plane_grad": live_frac * (N * 12 + N * Fd * 4) + 2 * G,
+                 "deform_gather": N * (12 + Fd * 4) + G, "permute_rows": N * 2 * 236,
                  "radix_scatter": R * 16, "radix_hist": R * 4, "expand_pairs": R * 8 + N * 16, "deform_bwd_prep": N * (59 * 8 + 256)}
 
     def roofline_of(k):
@@ -334,8 +335,18 @@ def run(args, make_step=None):
             roof["note"] = "saved activations: backward products only, live tiles only" if saved_on else "live tiles only"
         if dom == "deform_fwd":
             form = fdgs._lib.tuning_get("d1_form")
-            roof["note"] = (f"forward kernel form {form} (16 = 16 Gaussians per wave, two waves per SIMD; DESIGN 3.1), timed alone; its operand-stream copy "
-                            f"pack_weights ({kern.get('pack_weights', {}).get('avg_ms', 0.0):.4f} ms per launch) is a separate kernel in kernels_ms_per_step")
+            if "deform_gather" in kern:
+                roof["note"] = ("forward kernel form 8 (weight-stationary: the waves of a workgroup hold the five heads' first-layer matrices in registers, "
+                                "16-Gaussian tiles visit them through LDS; DESIGN 3.1), timed alone: ALL of the forward's matrix-core work (trunk + heads, "
+                                f"{flops_fwd / 1e9:.1f} GFLOP).  The HexPlane gather is a kernel of its own in this form -- deform_gather, "
+                                f"{kern['deform_gather']['avg_ms']:.4f} ms per launch, bound by L2 / texel traffic, in kernels_ms_per_step and rooflines; "
+                                f"gather + this kernel = {kern['deform_gather']['avg_ms'] + kern[dom]['avg_ms']:.4f} ms per forward "
+                                "(rounds 4 - 5, form 16 with the gather inside: 0.633 ms at 0.56 of the MFMA peak)")
+                roof["gather_plus_mlp_ms"] = kern["deform_gather"]["avg_ms"] + kern[dom]["avg_ms"]
+                roof["frac_with_the_gather_kernel_counted_in"] = mfma_flops[dom] / max(kern[dom]["launches_per_step"], 1e-9) / (roof["gather_plus_mlp_ms"] * 1e-3) / MFMA_F32_PEAK
+            else:
+                roof["note"] = (f"forward kernel form {form} (16 = 16 Gaussians per wave, two waves per SIMD; DESIGN 3.1), timed alone; its operand-stream copy "
+                                f"pack_weights ({kern.get('pack_weights', {}).get('avg_ms', 0.0):.4f} ms per launch) is a separate kernel in kernels_ms_per_step")
         roof.update(pmc_traffic(dom, args.workload, lib_sha16(fdgs)))
     rooflines = [roofline_of(k) for k in sorted(kern, key=lambda k: -kern[k]["ms_per_step"]) if kern[k]["ms_per_step"] >= 0.05 * kernel_sum]
 

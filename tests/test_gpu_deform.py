@@ -63,10 +63,10 @@ def test_deform_forward_backward_parity(cfg, n, activate):
 
 @pytest.mark.parametrize("cfg,n,t", [("dnerf_bouncingballs", 1000, None), ("hypernerf_default", 257, None), ("dynerf_default", 1531, None),
                                      ("dynerf_default", 31, None), ("dynerf_default", 40100, 0.37), ("hypernerf_default", 5000, 1.0)])
-@pytest.mark.parametrize("form", ["16", "32"])
+@pytest.mark.parametrize("form", ["8", "16", "32"])
 def test_deform_parity_other_forms_of_the_forward_kernel(cfg, n, t, form):
-    """The forms of the forward kernel that are NOT the default.  (Default since round 6, exercised by every other test here: tuning knob
-    d1_form = 8, the WEIGHT-STATIONARY form of csrc/deform_fwd_ws.h -- the waves of a workgroup hold the heads' first-layer matrices in
+    """The forms of the forward kernel that are NOT the default.  (Default since round 6: d1_form = 0 picks by shape -- the WEIGHT-STATIONARY form 8 at net_width 128 with up to two HexPlane
+    levels, form 16 otherwise; every form is forced here on every config.  d1_form = 8: the weight-stationary form of csrc/deform_fwd_ws.h -- the waves of a workgroup hold the heads' first-layer matrices in
     registers, 16-Gaussian tiles visit them through LDS, the gather is a kernel of its own.)
     d1_form = 16: one wave = 16 Gaussians on v_mfma_f32_16x16x4_f32, two waves per SIMD, W0 / W1 read as packed operand streams (the default
     of rounds 4 - 5); d1_form = 32: one wave = 32 Gaussians on v_mfma_f32_32x32x2_f32, one wave per SIMD (the default until round 4, and what
