@@ -151,14 +151,26 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a) {
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t contributor = 0, last = 0;
+    // staging pipeline (round 6; the backward has had it since round 3): list ids two rounds ahead, records one round ahead (the records'
+    // addresses depend on the ids) -- the two dependent memory round trips of a round no longer sit between its barrier and its arithmetic
+    const int n_list = (int)(range.y - range.x);
+    auto gid_of = [&](int r) -> uint32_t {
+        const int e = r * 256 + t;
+        return a.pair_gid[range.x + (e < n_list ? e : n_list - 1)];
+    };
+    uint32_t g_cur = 0u, g_nxt = 0u;
+    float4 rA, rB, rC;
+    if (rounds > 0) {
+        g_cur = gid_of(0);
+        if (rounds > 1) g_nxt = gid_of(1);
+        rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur];
+    }
     for (int r = 0; r < rounds; r++, toDo -= 256) {
         if (__syncthreads_count(done) == 256) break;
-        const int e = r * 256 + t;
-        if (range.x + e < range.y) {
-            const uint32_t gid = a.pair_gid[range.x + e];
-            sA[t] = a.recA[gid]; sB[t] = a.recB[gid]; sC[t] = a.recC[gid];
-        }
+        sA[t] = rA; sB[t] = rB; sC[t] = rC;      // (entries behind the end of the list are copies of its last entry: never read, j < lim)
         __syncthreads();
+        if (r + 1 < rounds) { g_cur = g_nxt; rA = a.recA[g_cur]; rB = a.recB[g_cur]; rC = a.recC[g_cur]; }
+        if (r + 2 < rounds) g_nxt = gid_of(r + 2);
         const int lim = toDo < 256 ? toDo : 256;
         for (int j = 0; !done && j < lim; j++) {
             contributor++;
