@@ -107,7 +107,9 @@ def _margins(m, thr, extent):
     dense = m.percent_dense * extent
     clone = torch.logical_and(torch.where(torch.norm(g[:, None], dim=-1) >= thr, True, False), mx <= dense)
     split = torch.logical_and(torch.where(g >= thr, True, False), mx > dense)
-    return g, mx, dense, clone, split
+    # the two DECISIONS themselves (the reported margins are float64 quotients of the same operands: a margin one ulp from zero may carry
+    # the other sign than the float32 comparison the reference makes -- what "flipped" means is read from these, never from a margin's sign)
+    return g, mx, dense, clone, split, (g >= thr), (mx > dense)
 
 
 def _prune_terms(m, min_opacity, extent, max_screen_size):
@@ -153,7 +155,7 @@ class ReferenceLeg:
         (:413-414), the clone mask is confirmed by the rows densify_and_clone hands to densification_postfix (:421-429)."""
         A = self.m
         n0 = int(A._xyz.shape[0])
-        g, mx, dense, clone, split = _margins(A, thr, extent)
+        g, mx, dense, clone, split, sel, big = _margins(A, thr, extent)
         xyz0 = A._xyz.detach().clone()
         seen = {"postfix": [], "split_mask": torch.zeros(n0, dtype=torch.bool, device=xyz0.device)}
         postfix, prune_points = A.densification_postfix, A.prune_points
@@ -176,7 +178,7 @@ class ReferenceLeg:
         assert torch.equal(seen["postfix"][0], xyz0[clone]), "the recorded clone rows are not the rows of the restated clone mask"
         assert torch.equal(seen["split_mask"], split), "the recorded split mask is not the restated split mask"
         assert len(seen["postfix"]) == (2 if bool(split.any()) else 1)
-        return g, mx, dense, clone, split
+        return g, mx, dense, clone, split, sel, big
 
     def prune(self, thr, opacity_thr, extent, size):
         A = self.m
@@ -245,8 +247,8 @@ class DropInLeg(ReferenceLeg):
 def _compare_events(ev, A, B, da, db, thr):
     """After one densification in both legs: same rows in the same order?  If not: the same SET of rows (matched by parent + slot)?  And
     which Gaussians were classified differently, with their margins to BOTH thresholds in BOTH legs."""
-    ga, mxa, dense, clone_a, split_a = da
-    gb, mxb, _, clone_b, split_b = db
+    ga, mxa, dense, clone_a, split_a, sel_a, big_a = da
+    gb, mxb, _, clone_b, split_b, sel_b, big_b = db
     ka, kb = _row_keys(clone_a, split_a), _row_keys(clone_b, split_b)
     ev["plan_A"] = (int((~split_a).sum()), int(clone_a.sum()), int(split_a.sum()))
     ev["plan_B"] = (int((~split_b).sum()), int(clone_b.sum()), int(split_b.sum()))
@@ -256,8 +258,9 @@ def _compare_events(ev, A, B, da, db, thr):
     name = lambda c, s: "split" if bool(s) else ("clone" if bool(c) else "keep")
     ev["differently_classified"] = [
         {"index": int(i), "A": name(clone_a[i], split_a[i]), "B": name(clone_b[i], split_b[i]),
-         "grad_margin_A": float(ga[i] / thr - 1.0), "grad_margin_B": float(gb[i] / thr - 1.0),
-         "size_margin_A": float(mxa[i] / dense - 1.0), "size_margin_B": float(mxb[i] / dense - 1.0)} for i in diff[:16]]
+         "grad_decision_A": bool(sel_a[i]), "grad_decision_B": bool(sel_b[i]), "size_decision_A": bool(big_a[i]), "size_decision_B": bool(big_b[i]),
+         "grad_margin_A": float(ga[i].double() / thr - 1.0), "grad_margin_B": float(gb[i].double() / thr - 1.0),
+         "size_margin_A": float(mxa[i].double() / dense - 1.0), "size_margin_B": float(mxb[i].double() / dense - 1.0)} for i in diff[:16]]
     # rows matched by identity (parent, slot): every row both legs hold
     sa, sb = torch.argsort(ka), torch.argsort(kb)
     ra, rb = sa[torch.isin(ka[sa], kb)], sb[torch.isin(kb[sb], ka)]
