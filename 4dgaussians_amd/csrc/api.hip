@@ -18,7 +18,7 @@ struct KnobDesc { const char* name; int Tuning::*field; int dflt; };
 const KnobDesc kKnobs[] = {
     {"D1_FORM", &Tuning::d1_form, 0}, {"D1_WGS", &Tuning::d1_wgs, -1}, {"D1_SPLIT", &Tuning::d1_split, 1}, {"SKIP_DEAD", &Tuning::skip_dead, 1},
     {"D4_MFMA", &Tuning::d4_mfma, -1}, {"D4_ROWS_KB", &Tuning::d4_rows_kb, -1}, {"TILE_CULL", &Tuning::tile_cull, 1}, {"RBWD_PPL", &Tuning::rbwd_ppl, -1},
-    {"TILE_ORDER", &Tuning::tile_order, 1}, {"ROW_COMPACT", &Tuning::row_compact, 1},
+    {"TILE_ORDER", &Tuning::tile_order, 1}, {"ROW_COMPACT", &Tuning::row_compact, 1}, {"D2_FORM", &Tuning::d2_form, 0},
 };
 Tuning tuning_from_environment() {       // runs once, from the static initialiser below (library load)
     Tuning t{};

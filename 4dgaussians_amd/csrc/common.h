@@ -64,6 +64,7 @@ struct Tuning {
     int rbwd_ppl;    // FDGS_RBWD_PPL    pixels per lane of the blending backward: -1 (default) = 2 up to 4 096 tiles, 4 above | 4 | 2 | 0 = the 256-thread form
     int tile_order;  // FDGS_TILE_ORDER  1 = the blending kernels take their tiles heaviest-first (per XCD), 0 = in image order
     int row_compact; // FDGS_ROW_COMPACT 1 = the deformation backward walks the non-zero ROWS (saved activations + ordered input), 0 = 32-row tiles
+    int d2_form;     // FDGS_D2_FORM     0 (default: the weight-stationary backward-data kernel, deform_bwd_ws.h, where it applies) | 32 (the 32-row kernel everywhere)
 };
 extern Tuning g_tune;
 

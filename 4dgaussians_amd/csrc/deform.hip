@@ -1634,6 +1634,8 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_kernel(BwdDev d) {
     }
 }
 
+#include "deform_bwd_ws.h"
+
 // ------------------------------------------------------------------------------------------------ D3 weight grads
 // dW[m][c] += sum_n DY[n][m] * X[n][c]   (m < W rows of DY, c < ncols of X), db[m] += sum_n DY[n][m];  K = #Gaussians.
 // One wave owns the WHOLE [W x ncols] product for its slice of Gaussians (16 accumulator tiles = 256 AGPRs at W = 128,
@@ -2594,6 +2596,23 @@ static void launch_bwd_data(hipStream_t s, int max_blocks, const BwdDev& d) {
 template <int WT, int FCH>
 struct BwdLauncher {
     static void go(hipStream_t s, int max_blocks, const BwdDev& d) {
+        // the weight-stationary form (deform_bwd_ws.h) where it applies: row lists, net_width 128, all five heads, C*L in {16, 32, 48}
+        if constexpr (WT == 4 && (FCH % 2) == 0 && FCH <= 6) {
+            bool all_on = true;
+            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) all_on = all_on && d.p.head_on[hd];
+            if (d.sv_h1 && d.s.rows && all_on && g_tune.d2_form != 32) {
+                static int cus = 0;
+                if (cus == 0) {
+                    int dev = 0;
+                    (void)hipGetDevice(&dev);
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+                }
+                int blocks = cus;
+                if (blocks > max_blocks * 8) blocks = max_blocks * 8;      // (never more workgroups than 16-row tiles)
+                hipLaunchKernelGGL((deform_bwd_data_ws_kernel<FCH / 2>), dim3(blocks), dim3(256), 0, s, d);
+                return;
+            }
+        }
         if (d.sv_h1 && d.s.rows) launch_bwd_data<WT, FCH, true, true>(s, max_blocks, d);
         else if (d.sv_h1) launch_bwd_data<WT, FCH, true>(s, max_blocks, d);
         else launch_bwd_data<WT, FCH, false>(s, max_blocks, d);

@@ -1,0 +1,347 @@
+// deform_bwd_ws.h -- D2 (backward-data of the deformation MLP) in a WEIGHT-STATIONARY form (round 6).  Included by deform.hip inside namespace
+// fdgs, after the 32-row kernel whose structures (BwdDev, head_k / head_off, ROW_PAD) and memory formats it shares: the row list, the compact
+// gradient rows G [position][64], the saved relu(h1) / ReLU bits of the forward, DH1 / DHID / DFEAT indexed by list position -- D3 and D4 do
+// not know which form ran.  Results differ from the 32-row kernel by summation order only.
+//
+// Why.  The 32-row kernel gives a wave its 32 rows and streams every weight of every layer past them (W1^T of five heads = 320 KB per 32
+// rows from L2), one wave per SIMD with a long tail of stages nothing overlaps: 0.42 of the f32 MFMA peak on the shell scene, where it is
+// the largest kernel of the frame (0.75 ms).  This is D1's medicine (deform_fwd_ws.h) for the transposed products: the weights stay, the
+// rows move -- and because the reduction of dhid = sum_h W1_h^T dh1_h runs over the OUTPUT features of the heads' first layers, the split
+// over the four waves is a split of K:
+//     wave w owns first-layer features 32 w .. 32 w + 31 of every head: their W1 rows (all 128 columns: 5 x 64 registers, never reloaded),
+//     their W2 columns, their slice of relu(h1), their columns of dW2;
+//     per 16-row tile and head: dh1 = (W2^T G) . relu'(h1) for its 32 features (the D layout of v_mfma_f32_16x16x4_f32 IS the B layout of
+//     the next product: no exchange), stored as DH1; dW2 += G^T relu(h1) for its 32 columns; then 64 MFMAs add W1^T dh1 into ITS partial
+//     sum of dhid [128 x 16] (8 accumulator tiles);
+//     ONE exchange per tile: the four partial dhid meet in LDS, every wave adds up the 32 features it owns, applies relu'(hidden), stores
+//     DHID, and multiplies them with its rows of W0 (partial dfeat, summed by a short epilogue).
+// Nothing streams from L2 in the tile loop except the tile's own data (16 gradient rows, 5 x 16 x 32 saved activations per wave, 32 bytes of
+// ReLU bits per row), and that arrives by LDS-DMA (global_load_lds_dwordx4, guide: "glds"): 320 registers of weights + 32 of partial sums +
+// 32 of dW2 sums leave no room for loads in flight.  A DMA writes its wave's LDS park lane-linearly, so the park's swizzle (conflict-free
+// transposed reads for the dW2 product, whose reduction runs over the ROWS) is applied to the SOURCE addresses.  Every park is wave-private,
+// filled a whole iteration before it is read, and retired by `s_waitcnt vmcnt(8)` -- at least 16 vector-memory operations (DMAs and stores)
+// are issued between a DMA and the first read of its park, completion is in order, so "at most 8 in flight" covers it without ever waiting
+// for the stores just issued (a vmcnt(0) would: deform_fwd_ws.h, lesson 1).  The compiler sees no load in the loop: the DMAs are asm.
+//
+// Applies to: row-list form (saved activations, ordered input), net_width 128, all five heads on, C*L in {16, 32, 48}.  Everything else runs the
+// 32-row kernel (tuning knob d2_form = 32 forces it everywhere).
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {       // 64 lanes x 16 bytes -> LDS [lds_dst + 16 lane]
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {        // 64 lanes x 4 bytes -> LDS [lds_dst + 4 lane]
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#define WS2_WAIT_PARKS() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define WS2_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define WS2_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WS2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+#ifdef FDGS_PROFILE_D2WS
+#define WS2_TICK(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[ph] += t_ - pt; pt = t_; } while (0)
+#else
+#define WS2_TICK(ph) do { } while (0)
+#endif
+
+template <int FU>
+__global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
+    constexpr int W = 128, NH = FDGS_NUM_HEADS, LDW = W + 4, XLD = W + 4, F = 16 * FU, PLD = F + 4;
+    const fdgs_deform_params& p = d.p;
+    // parks (LDS-DMA destinations, lane-linear 16-byte chunks, swizzled through the source addresses):
+    //   h1 [head][wave]: chunk (row g, c8 = features 4 c8 .. + 3 of the wave's 32) at slot 8 g + (c8 ^ (g & 7))
+    //   g  [buffer]: the tile's 16 gradient rows, chunk (g, c16) at slot 16 g + (c16 ^ g) -- ONE copy per workgroup, a quarter DMA'd by each wave:
+    //      readable after a barrier that every wave passed behind its own wait (the top of the next iteration)
+    //   ri [stage][wave]: the tile's 16 row-list entries;  hm [wave]: uint4 (g, half t) at slot 16 t + g: the forward's ReLU bits of the trunk
+    __shared__ __attribute__((aligned(16))) float park_h1[NH][4][512];
+    __shared__ __attribute__((aligned(16))) float park_g[2][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t park_ri[2][4][64];
+    __shared__ __attribute__((aligned(16))) uint32_t park_hm[4][256];
+    __shared__ __attribute__((aligned(16))) float xp[4][16 * XLD];      // the waves' partial dhid [wave][row][feature]
+    __shared__ __attribute__((aligned(16))) float pl[4][16 * PLD];      // the waves' partial dfeat [wave][row][input feature]
+    __shared__ __attribute__((aligned(16))) float w2l[59 * LDW];        // the heads' W2, row-major (rows 0 .. 10: the k <= 4 heads, 11 .. 58: SH)
+    __shared__ __attribute__((aligned(16))) float w0l[W * PLD];         // W0, row-major
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
+    for (int hd = 0; hd < NH; hd++)
+        for (int i = tid; i < head_k(hd) * (W / 4); i += 256) {
+            const int r = i / (W / 4), c4 = i - r * (W / 4);
+            *reinterpret_cast<float4*>(w2l + (head_row0(hd) + r) * LDW + 4 * c4) = reinterpret_cast<const float4*>(p.w2[hd])[i];
+        }
+    for (int i = tid; i < W * (F / 4); i += 256) {
+        const int r = i / (F / 4), c4 = i - r * (F / 4);
+        *reinterpret_cast<float4*>(w0l + r * PLD + 4 * c4) = reinterpret_cast<const float4*>(p.w0)[i];
+    }
+    // ---- the stationary operands.  A-lane (i = n, k = q) of v_mfma_f32_16x16x4_f32:
+    //   w1r[h][to][t][r] = W1_h[out = 32 w + 16 t + 4 q + r][in = 16 to + n]     dhid[in] += W1[out][in] dh1[out]
+    // (W0 and the W2 are read from LDS where they are used: 320 registers of W1 + 64 of running sums are what the register file holds)
+    float w1r[NH][8][2][4];
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int to = 0; to < 8; to++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) w1r[h][to][t][r] = p.w1[h][(size_t)(32 * w + 16 * t + 4 * q + r) * W + 16 * to + n];
+    // sums that live in registers for the whole launch: dW2 of the wave's 32 columns (D-lane (n, q) register r: row 4 q + r of the column
+    // group, column 32 w + 16 t + n) -- the four k <= 4 heads share one group (their 11 rows ARE columns 0 .. 10 of G) -- and db2
+    f32x4 dws[2] = {zero4(), zero4()}, dwh[3][2];
+#pragma unroll
+    for (int og = 0; og < 3; og++) { dwh[og][0] = zero4(); dwh[og][1] = zero4(); }
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (int)as_const(d.s.counters)[5] * 2;      // 16-row tiles of the (padded) row list
+    const int G_ = (int)gridDim.x;
+    const unsigned a_h1 = (unsigned)(size_t)&park_h1[0][w][0], a_g = (unsigned)(size_t)&park_g[0][256 * w], a_ri = (unsigned)(size_t)&park_ri[0][w][0],
+                   a_hm = (unsigned)(size_t)&park_hm[w][0];
+    constexpr unsigned S_H1 = 4 * 512 * 4, S_G = 1024 * 4, S_RI = 4 * 64 * 4;      // bytes between heads / buffers / stages
+    // per-lane constants of the DMA source addresses
+    const int h1_g[2] = {lane >> 3, 8 + (lane >> 3)};
+    const int h1_c8[2] = {(lane & 7) ^ ((lane >> 3) & 7), (lane & 7) ^ ((lane >> 3) & 7)};      // (g & 7 is the same for g and g + 8)
+    auto dma_ri = [&](int tile, int stage) {
+        glds4(d.s.rows + (size_t)tile * 16 + n, a_ri + S_RI * stage);
+    };
+    auto dma_g = [&](int tile, int buf) {      // (this wave's quarter: rows 4 w .. 4 w + 3)
+        const int slot = 64 * w + lane, g = slot >> 4, c16 = (slot & 15) ^ g;
+        glds16(d.s.G + ((size_t)tile * 16 + g) * GCOLS + 4 * c16, a_g + S_G * buf);
+    };
+    auto dma_hm = [&](int stage) {
+        const uint32_t row = park_ri[stage][w][n] & ~ROW_PAD;
+        const int t = q & 1;
+        glds16(reinterpret_cast<const uint4*>(d.sv_hmask) + ((size_t)(row >> 5) * 64 + 32 * t + (row & 31u)), a_hm);
+    };
+    auto dma_h1 = [&](int h, int stage) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint32_t row = park_ri[stage][w][h1_g[e]] & ~ROW_PAD;
+            glds16(d.sv_h1 + ((size_t)h * d.s.Npad + row) * W + 32 * w + 4 * h1_c8[e], a_h1 + S_H1 * h + 1024u * e);
+        }
+    };
+
+    // ---- one head's share of a tile, up to the operand of the main product
+    // dh[t] (D-lane (n = row, q) register r) = dh1[row n][feature 32 w + 16 t + 4 q + r] -- also the B operand (k = q, step (t, r)) of W1^T dh1
+    // (opaque copies of the lane coordinates per call: the dozens of LDS offsets below are loop invariants, and hoisted out of the tile loop
+    // they would each hold a register for the whole launch -- this kernel has none to spare; recomputed they are VALU work inside MFMA shadows)
+    const int n_lane = n, q_lane = q;
+    auto phase = [&](int h, int tile, int gbuf, f32x4* dh) {
+        int n = n_lane, q = q_lane;
+        asm volatile("" : "+v"(n), "+v"(q));
+        const float* gp = park_g[gbuf];
+        const float* hp = park_h1[h][w];
+        dh[0] = zero4(); dh[1] = zero4();
+        if (h != FDGS_HEAD_SHS) {
+            const int k = head_k(h), o = q < k ? q : k - 1, col = head_off(h) + o;
+            const float b_raw = gp[64 * n + 4 * ((col >> 2) ^ n) + (col & 3)];
+            const float b = q < k ? b_raw : 0.f;
+            const float* wr = w2l + (head_row0(h) + o) * LDW + 32 * w + n;
+            dh[0] = mm16(wr[0], b, dh[0]);
+            dh[1] = mm16(wr[16], b, dh[1]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const float4 bv = *reinterpret_cast<const float4*>(gp + 64 * n + 4 * ((4 + 4 * s + q) ^ n));
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float* wr = w2l + (11 + 16 * s + 4 * q + c) * LDW + 32 * w + n;
+                    dh[0] = mm16(wr[0], bb[c], dh[0]);
+                    dh[1] = mm16(wr[16], bb[c], dh[1]);
+                }
+            }
+        }
+        // relu'(h1) from the saved activations (natural layout), then DH1
+        float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n) * W + 32 * w + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * (8 * n + ((4 * t + q) ^ (n & 7))));
+            dh[t][0] = hv.x > 0.f ? dh[t][0] : 0.f; dh[t][1] = hv.y > 0.f ? dh[t][1] : 0.f;
+            dh[t][2] = hv.z > 0.f ? dh[t][2] : 0.f; dh[t][3] = hv.w > 0.f ? dh[t][3] : 0.f;
+            *reinterpret_cast<float4*>(slab + 16 * t) = make_float4(dh[t][0], dh[t][1], dh[t][2], dh[t][3]);
+        }
+        // dW2[col][feature] += sum_rows G[row][col] relu(h1)[row][feature]: the reduction runs over the ROWS -- both operands are read
+        // TRANSPOSED from the parks (A-lane (i = n: column, k = q) step c: row 4 q + c; B-lane (j = n: feature 16 t + n, k = q) likewise)
+        float bt[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int g = 4 * q + c;
+                bt[t][c] = hp[4 * (8 * g + ((4 * t + (n >> 2)) ^ (g & 7))) + (n & 3)];
+            }
+        if (h != FDGS_HEAD_SHS) {
+            const int k = head_k(h), off = head_off(h);
+            const bool mine = n >= off && n < off + k;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int g = 4 * q + c;
+                const float a_raw = gp[64 * g + 4 * ((n >> 2) ^ g) + (n & 3)];
+                if (h == 0) dbs[0] += a_raw;       // (db2 of the four k <= 4 heads: all of columns 0 .. 15, once per tile)
+                const float a = mine ? a_raw : 0.f;
+                dws[0] = mm16(a, bt[0][c], dws[0]);
+                dws[1] = mm16(a, bt[1][c], dws[1]);
+            }
+        } else {
+#pragma unroll
+            for (int og = 0; og < 3; og++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int g = 4 * q + c;
+                    const float a = gp[64 * g + 4 * ((4 + 4 * og + (n >> 2)) ^ g) + (n & 3)];
+                    dbs[1 + og] += a;
+                    dwh[og][0] = mm16(a, bt[0][c], dwh[og][0]);
+                    dwh[og][1] = mm16(a, bt[1][c], dwh[og][1]);
+                }
+        }
+    };
+
+#ifdef FDGS_PROFILE_D2WS
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt = __builtin_amdgcn_s_memtime();
+#endif
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        // ---- prologue: the first tile's parks, the second tile's row-list entries; the first head's dh1
+        const int t1 = tile + G_ < ntiles ? tile + G_ : tile;
+        dma_ri(tile, 0); dma_ri(t1, 1);
+        WS2_WAIT_ALL();
+        dma_g(tile, 0); dma_hm(0);
+#pragma unroll
+        for (int h = 0; h < NH; h++) dma_h1(h, 0);
+        WS2_WAIT_ALL();
+        __syncthreads();      // (w2l, w0l; every wave's quarter of the first tile's gradient rows)
+        f32x4 dh_cur[2];
+        int it = 0, prev = -1;
+        uint32_t hbits_prev = 0u;
+        // the exchange of the previous tile: every wave adds up the partial dhid of the 32 hidden features it owns, applies relu'(hidden),
+        // stores DHID and multiplies with its rows of W0; then the partial dfeat are added and stored
+        auto finish_prev = [&]() {
+            int n = n_lane, q = q_lane;
+            asm volatile("" : "+v"(n), "+v"(q));
+            WS2_BARRIER();            // every wave's partial sums of tile `prev` are in xp
+            f32x4 dhid[2];
+            float* drow = d.s.DHID + ((size_t)prev * 16 + n) * W + 32 * w + 4 * q;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                float4 s = *reinterpret_cast<const float4*>(&xp[0][n * XLD + 32 * w + 16 * t + 4 * q]);
+#pragma unroll
+                for (int ww = 1; ww < 4; ww++) {
+                    const float4 v = *reinterpret_cast<const float4*>(&xp[ww][n * XLD + 32 * w + 16 * t + 4 * q]);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                const uint32_t b = hbits_prev >> (4 * t);
+                dhid[t][0] = (b & 1u) ? s.x : 0.f; dhid[t][1] = (b & 2u) ? s.y : 0.f; dhid[t][2] = (b & 4u) ? s.z : 0.f; dhid[t][3] = (b & 8u) ? s.w : 0.f;
+                *reinterpret_cast<float4*>(drow + 16 * t) = make_float4(dhid[t][0], dhid[t][1], dhid[t][2], dhid[t][3]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < FU; ct++) {
+                f32x4 df = zero4();
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) df = mm16(w0l[(32 * w + 16 * t + 4 * q + r) * PLD + 16 * ct + n], dhid[t][r], df);
+                *reinterpret_cast<float4*>(&pl[w][n * PLD + 16 * ct + 4 * q]) = make_float4(df[0], df[1], df[2], df[3]);
+            }
+            WS2_BARRIER();            // xp may be overwritten; the partial dfeat are complete
+            if (tid < 16 * (F / 4)) {
+                const int g = tid / (F / 4), c = tid - g * (F / 4);
+                float4 s = *reinterpret_cast<const float4*>(&pl[0][g * PLD + 4 * c]);
+#pragma unroll
+                for (int ww = 1; ww < 4; ww++) {
+                    const float4 v = *reinterpret_cast<const float4*>(&pl[ww][g * PLD + 4 * c]);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                *reinterpret_cast<float4*>(d.s.DFEAT + ((size_t)prev * 16 + g) * F + 4 * c) = s;
+            }
+        };
+        for (; tile < ntiles; tile += G_, it ^= 1) {
+            WS2_TICK(0);
+            const bool has_next = tile + G_ < ntiles;
+            const int nxt = has_next ? tile + G_ : tile, nxt2 = tile + 2 * G_ < ntiles ? tile + 2 * G_ : nxt;
+            // (every wave waits for ITS quarter of this tile's gradient rows before the barrier that opens them to the others)
+            WS2_WAIT_PARKS();
+            if (prev >= 0) finish_prev();
+            WS2_TICK(1);
+            // this tile's ReLU bits of the trunk: D-lane (n, q), tile t, register r = hidden feature 32 w + 16 t + 4 q + r = word r, bit q + 4 w of the
+            // uint4 (row, half t) in the forward's layout (deform_fwd_ws.h: trunk)
+            WS2_WAIT_PARKS();
+            uint32_t hbits = 0u;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint4 hm = *reinterpret_cast<const uint4*>(&park_hm[w][4 * (16 * t + n)]);
+                const uint32_t sh = (uint32_t)(q + 4 * w);
+                hbits |= (((hm.x >> sh) & 1u) | (((hm.y >> sh) & 1u) << 1) | (((hm.z >> sh) & 1u) << 2) | (((hm.w >> sh) & 1u) << 3)) << (4 * t);
+            }
+            WS2_LDS_DONE();
+            // the next tile's gradient rows and ReLU bits, the row-list entries of the tile after it (stage `it` held this tile's: no longer needed)
+            dma_g(nxt, it ^ 1); dma_hm(it ^ 1); dma_ri(nxt2, it);
+            phase(0, tile, it, dh_cur);
+            f32x4 acc[8];
+#pragma unroll
+            for (int to = 0; to < 8; to++) acc[to] = zero4();
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                // park h is free (its phase ran inside the previous product): the next tile's rows of this head
+                WS2_LDS_DONE();
+                dma_h1(h, it ^ 1);
+                f32x4 dh_nxt[2];
+                // the main product of head h: 64 MFMAs on 8 independent accumulators; the next head's phase (of the next tile behind the last head)
+                // rides inside it
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+#pragma unroll
+                        for (int to = 0; to < 8; to++) acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
+                    }
+                    if (t == 0) {
+                        WS2_WAIT_PARKS();
+                        if (h + 1 < NH) phase(h + 1, tile, it, dh_nxt);
+                    }
+                }
+                if (h + 1 < NH) { dh_cur[0] = dh_nxt[0]; dh_cur[1] = dh_nxt[1]; }
+            }
+            WS2_TICK(2);
+            // this wave's partial dhid into the exchange (the second barrier of finish_prev freed it)
+#pragma unroll
+            for (int to = 0; to < 8; to++)
+                *reinterpret_cast<float4*>(&xp[w][n * XLD + 16 * to + 4 * q]) = make_float4(acc[to][0], acc[to][1], acc[to][2], acc[to][3]);
+            hbits_prev = hbits;
+            prev = tile;
+            WS2_TICK(3);
+        }
+        finish_prev();
+    }
+    WS2_WAIT_ALL();
+    // ---- flush: the wave's columns of dW2 (one global atomic per element and workgroup), db2 from wave 0
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int f = 32 * w + 16 * t + n;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = 4 * q + r;
+            const int hd = col < 3 ? 0 : col < 6 ? 1 : col < 10 ? 2 : 3;
+            if (col <= 10 && dws[t][r] != 0.f) atomicAdd(&d.d_w2[hd][(size_t)(col - head_off(hd)) * W + f], dws[t][r]);
+#pragma unroll
+            for (int og = 0; og < 3; og++)
+                if (dwh[og][t][r] != 0.f) atomicAdd(&d.d_w2[FDGS_HEAD_SHS][(size_t)(16 * og + col) * W + f], dwh[og][t][r]);
+        }
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++) dbs[gq] = sum_lane_groups(dbs[gq]);
+    if (w == 0 && q == 0) {
+        const int hd = n < 3 ? 0 : n < 6 ? 1 : n < 10 ? 2 : 3;
+        if (n <= 10 && dbs[0] != 0.f) atomicAdd(&d.d_b2[hd][n - head_off(hd)], dbs[0]);
+#pragma unroll
+        for (int og = 0; og < 3; og++)
+            if (dbs[1 + og] != 0.f) atomicAdd(&d.d_b2[FDGS_HEAD_SHS][16 * og + n], dbs[1 + og]);
+    }
+#ifdef FDGS_PROFILE_D2WS
+    if (d.prof && lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&d.prof[i], pacc[i]);
+        atomicAdd(&d.prof[8], 1ull);
+    }
+#endif
+}

@@ -503,9 +503,12 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
     # "rows": the default -- on ordered input with saved activations the backward walks the non-zero ROWS (row_compact = 1: row lists, compact
     # gradient rows, activations fetched through the list); "1": the 32-row tile lists (row_compact = 0); "0": every tile
     # "rows2": the row lists built by the two-launch form (tile_compact_kernel + row_gather_kernel: what sets of more than 16 384 tiles take)
-    for skip in ("rows", "rows2", "1", "0"):
+    # "rows_d2_32": the row lists walked by the 32-row backward-data kernel (d2_form = 32) where the default is the weight-stationary one
+    # (csrc/deform_bwd_ws.h: net_width 128 with all five heads, i.e. the dynerf configuration here)
+    for skip in ("rows", "rows_d2_32", "rows2", "1", "0"):
         set_knob("skip_dead", "0" if skip == "0" else "1")
-        set_knob("row_compact", {"rows": "1", "rows2": "2"}.get(skip, "0"))
+        set_knob("row_compact", {"rows": "1", "rows_d2_32": "1", "rows2": "2"}.get(skip, "0"))
+        set_knob("d2_form", "32" if skip == "rows_d2_32" else "0")
         gpu_in = [x.to(dev).requires_grad_(i < 5) for i, x in enumerate(ins)]
         out = fd.deformation.deform(net, *gpu_in[:4], shs=gpu_in[4], time=0.43, activate=True, ordered=ordered)
         params = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
@@ -525,7 +528,7 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
         assert res["rows"][1][0] == res["rows2"][1][0] == -(-nrows // chunk) * chunk // 32 and res["rows"][1][0] <= live
     else:           # unordered input keeps the per-corner plane-gradient kernel, which walks Gaussians: tile lists
         assert res["rows"][1][0] == res["rows2"][1][0] == live
-    for mode in ("rows", "rows2", "1"):
+    for mode in ("rows", "rows_d2_32", "rows2", "1"):
         worst = {}
         for k, a, b in zip(names, res[mode][0], res["0"][0]):
             if b is None:
