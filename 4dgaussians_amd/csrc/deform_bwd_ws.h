@@ -58,6 +58,14 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
 #define WS2_TICK(ph) do { } while (0)
 #endif
 
+// The main products of the first WS2_ASM_MFMA heads are inline assembly with the A operand IN an accumulation register: the register
+// allocator parks those heads' weights in AGPRs as spill slots and copies each one to a VGPR in front of its MFMA (v_accvgpr_read + two wait
+// states, ~15 cycles out of every MFMA's shadow: 128 of a tile's 320); told that the operand lives there ("a"), it uses it in place: shell
+// scene 0.614 -> 0.561 ms.  (Three heads measure the same as two; all five would need 320 AGPRs.)
+#ifndef WS2_ASM_MFMA
+#define WS2_ASM_MFMA 2
+#endif
+
 template <int FU>
 __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
     constexpr int W = 128, NH = FDGS_NUM_HEADS, LDW = W + 4, XLD = W + 4, F = 16 * FU, PLD = F + 4;
@@ -399,7 +407,20 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
                     const int t = grp >> 2, r = grp & 3;
                     if (grp == 0) WS2_WAIT_PARKS();
 #pragma unroll
-                    for (int to = 0; to < 8; to++) acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
+                    for (int to = 0; to < 8; to++) {
+#if WS2_ASM_MFMA > 0
+                        // (A operand straight from an accumulation register: the compiler parks these weights in AGPRs anyway and copies each
+                        // one to a VGPR in front of its MFMA -- a VALU instruction + two wait states out of every MFMA's shadow)
+                        // (the compiler's hazard recogniser does not look into the statement: the B operand may have been written by the VALU
+                        // instruction right in front of a group -- two wait states in front of the first MFMA of every group)
+                        if (h < WS2_ASM_MFMA) {
+                            if (to == 0) asm("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[to]) : "a"(w1r[h][to][t][r]), "v"(dh_cur[t][r]));
+                            else asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[to]) : "a"(w1r[h][to][t][r]), "v"(dh_cur[t][r]));
+                        }
+                        else
+#endif
+                        acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
+                    }
                     if (h + 1 < NH - 1) { if (grp < 4) small_slot(grp, h + 1, tile, it, dh_nxt, R); }
                     else if (h + 1 == NH - 1) sh_slot(grp, tile, it, dh_nxt, R);
                     if (prev >= 0) {

@@ -43,12 +43,14 @@ int fdgs_abi_version(void);
  * roofline measurement).  fdgs_timing_report synchronises the device and writes "kernel_name count total_ms" lines. */
 int fdgs_timing_enable(int on);
 int fdgs_timing_report(char* buf, size_t buflen, int reset);
-/* Development / test knobs (ABI 4; ten since ABI 5).  The library holds ONE table of integer knobs; it is filled from the environment variables
+/* Development / test knobs (ABI 4; ten since ABI 5, eleven since round 6).  The library holds ONE table of integer knobs; it is filled from the environment variables
  * FDGS_<NAME> once, when the library is loaded, and afterwards changes only through fdgs_tuning_set -- no entry point reads the
  * environment.  Knobs select between equivalent kernel forms or launch shapes (same results up to summation order), never semantics:
  *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (-1 = by image size | 4 | 2 | 0),
  *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order), row_compact (1 = the deformation backward walks
- *   the non-zero rows instead of the non-zero 32-row tiles where it can; 2 = the same with the row lists built by the two-launch form).
+ *   the non-zero rows instead of the non-zero 32-row tiles where it can; 2 = the same with the row lists built by the two-launch form),
+ *   d2_form (0 = the weight-stationary backward-data kernel where it applies -- row lists, net_width 128, all five heads, C*L 32 or 48 --, 32 = the
+ *   32-row kernel everywhere).
  * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
  * set knobs between frames.  fdgs_tuning_reset restores the load-time values.  See INTEGRATION.md ("Knobs"). */
 int fdgs_tuning_set(const char* name, int value);
