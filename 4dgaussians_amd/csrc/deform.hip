@@ -2596,11 +2596,12 @@ static void launch_bwd_data(hipStream_t s, int max_blocks, const BwdDev& d) {
 template <int WT, int FCH>
 struct BwdLauncher {
     static void go(hipStream_t s, int max_blocks, const BwdDev& d) {
-        // the weight-stationary form (deform_bwd_ws.h) where it applies: row lists, net_width 128, all five heads, C*L in {16, 32, 48}
+        // the weight-stationary form (deform_bwd_ws.h) where it applies: row lists, net_width 128, C*L in {32, 48}, all five heads (dynerf) or the
+        // three of position / scale / rotation (hypernerf, dnerf)
         if constexpr (WT == 4 && (FCH % 2) == 0 && FCH <= 6) {
-            bool all_on = true;
-            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) all_on = all_on && d.p.head_on[hd];
-            if (d.sv_h1 && d.s.rows && all_on && g_tune.d2_form != 32) {
+            int mask = 0;
+            for (int hd = 0; hd < FDGS_NUM_HEADS; hd++) mask |= d.p.head_on[hd] ? 1 << hd : 0;
+            if (d.sv_h1 && d.s.rows && (mask == 31 || mask == 7) && g_tune.d2_form != 32) {
                 static int cus = 0;
                 if (cus == 0) {
                     int dev = 0;
@@ -2609,7 +2610,8 @@ struct BwdLauncher {
                 }
                 int blocks = cus;
                 if (blocks > max_blocks * 8) blocks = max_blocks * 8;      // (never more workgroups than 16-row tiles)
-                hipLaunchKernelGGL((deform_bwd_data_ws_kernel<FCH / 2>), dim3(blocks), dim3(256), 0, s, d);
+                if (mask == 31) hipLaunchKernelGGL((deform_bwd_data_ws_kernel<FCH / 2, 31>), dim3(blocks), dim3(256), 0, s, d);
+                else hipLaunchKernelGGL((deform_bwd_data_ws_kernel<FCH / 2, 7>), dim3(blocks), dim3(256), 0, s, d);
                 return;
             }
         }

@@ -23,8 +23,9 @@
 // are issued between a DMA and the first read of its park, completion is in order, so "at most 8 in flight" covers it without ever waiting
 // for the stores just issued (a vmcnt(0) would: deform_fwd_ws.h, lesson 1).  The compiler sees no load in the loop: the DMAs are asm.
 //
-// Applies to: row-list form (saved activations, ordered input), net_width 128, all five heads on, C*L in {16, 32, 48}.  Everything else runs the
-// 32-row kernel (tuning knob d2_form = 32 forces it everywhere).
+// Applies to: row-list form (saved activations, ordered input), net_width 128, C*L in {32, 48}, all five heads (dynerf) or the three of position /
+// scale / rotation (hypernerf: template parameter HM, the kernel is written for any set of three or more heads that starts with a k <= 4 head).
+// Everything else runs the 32-row kernel (tuning knob d2_form = 32 forces it everywhere).
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {       // 64 lanes x 16 bytes -> LDS [lds_dst + 16 lane]
     unsigned keep;
@@ -38,10 +39,11 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
 }
 // (a wave issues 25 - 26 vector-memory operations per tile; between a DMA and the first read of its park lie at least 19 of them: "at most 16
 // in flight" retires the DMA and never waits for a store younger than half a tile -- stores take microseconds to be acknowledged)
+// (with K of the five heads active the numbers are 4 K + 5 per tile and 4 K - 1 between a DMA and its park's first read: vmcnt(4 K - 4))
 #ifdef WS2_X_NO_WAIT
 #define WS2_WAIT_PARKS() do { } while (0)
 #else
-#define WS2_WAIT_PARKS() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
+#define WS2_WAIT_PARKS() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NH - 4) : "memory")
 #endif
 #define WS2_WAIT_G() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")      // (twelve operations follow the DMA of the gradient rows up to the barrier behind the second product)
 #define WS2_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -66,9 +68,16 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
 #define WS2_ASM_MFMA 2
 #endif
 
-template <int FU>
+// HM: the active heads (bit hd; at least three, the SH head -- if active -- last by construction of the head numbering).  Arrays per head are
+// indexed by the head's POSITION among the active ones (= its slab of saved activations / DH1, fdgs_deform_bwd's head_slot).
+__host__ __device__ constexpr int ws2_popc(int m) { return m == 0 ? 0 : (m & 1) + ws2_popc(m >> 1); }
+__host__ __device__ constexpr int ws2_nth(int m, int i, int hd = 0) { return (m & 1) ? (i == 0 ? hd : ws2_nth(m >> 1, i - 1, hd + 1)) : ws2_nth(m >> 1, i, hd + 1); }
+
+template <int FU, int HM>
 __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
-    constexpr int W = 128, NH = FDGS_NUM_HEADS, LDW = W + 4, XLD = W + 4, F = 16 * FU, PLD = F + 4;
+    constexpr int W = 128, NH = ws2_popc(HM), LDW = W + 4, XLD = W + 4, F = 16 * FU, PLD = F + 4;
+    static_assert(NH >= 3 && HM < 32 && ws2_nth(HM, 0) != FDGS_HEAD_SHS, "three or more heads, a k <= 4 head first");
+    constexpr bool HAS_SH = (HM >> FDGS_HEAD_SHS) & 1;
     const fdgs_deform_params& p = d.p;
     // parks (LDS-DMA destinations, lane-linear 16-byte chunks, swizzled through the source addresses):
     //   h1 [head][wave]: chunk (row g, c8 = features 4 c8 .. + 3 of the wave's 32) at slot 8 g + (c8 ^ (g & 7))
@@ -84,8 +93,8 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
     __shared__ __attribute__((aligned(16))) float w2l[59 * LDW];        // the heads' W2, row-major (rows 0 .. 10: the k <= 4 heads, 11 .. 58: SH)
     __shared__ __attribute__((aligned(16))) float w0l[W * PLD];         // W0, row-major
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, q = lane >> 4;
-    for (int hd = 0; hd < NH; hd++)
-        for (int i = tid; i < head_k(hd) * (W / 4); i += 256) {
+    for (int hd = 0; hd < FDGS_NUM_HEADS; hd++)
+        for (int i = tid; ((HM >> hd) & 1) && i < head_k(hd) * (W / 4); i += 256) {
             const int r = i / (W / 4), c4 = i - r * (W / 4);
             *reinterpret_cast<float4*>(w2l + (head_row0(hd) + r) * LDW + 4 * c4) = reinterpret_cast<const float4*>(p.w2[hd])[i];
         }
@@ -104,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) w1r[h][to][t][r] = p.w1[h][(size_t)(32 * w + 16 * t + 4 * q + r) * W + 16 * to + n];
+                for (int r = 0; r < 4; r++) w1r[h][to][t][r] = p.w1[ws2_nth(HM, h)][(size_t)(32 * w + 16 * t + 4 * q + r) * W + 16 * to + n];
     // sums that live in registers for the whole launch: dW2 of the wave's 32 columns (D-lane (n, q) register r: row 4 q + r of the column
     // group, column 32 w + 16 t + n) -- the four k <= 4 heads share one group (their 11 rows ARE columns 0 .. 10 of G) -- and db2
     f32x4 dws[2] = {zero4(), zero4()}, dwh[3][2];
@@ -175,7 +184,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
 #define WS2_LDF4(base, off) (*reinterpret_cast<const float4*>((base) + (off)))
 #define WS2_OPAQUE(v, key) asm("" : "+v"(v) : "s"(tile), "s"(key))
     // slots of a k <= 4 head: 0 reads | 1 dh1 | 2 mask, DH1, transposed reads | 3 dW2
-    auto small_slot = [&](int slot, int h, int tile, int gbuf, f32x4* dh, Rider& R) {
+    auto small_slot = [&](int slot, int h, int pi, int tile, int gbuf, f32x4* dh, Rider& R) {      // (h: the head, pi: its position among the active ones)
         const int k = head_k(h), off = head_off(h);
         if (slot == 0) {
             WS2_COORDS_K(64 + 8 * h)
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             R.wa[0] = WS2_LDF(lds_w2, wo); R.wa[1] = WS2_LDF(lds_w2, wo + 64);
             int hn = o_hn;
             WS2_OPAQUE(hn, 65 + 8 * h);
-            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * h); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * h);
+            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * pi); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * pi);
         } else if (slot == 1) {
             const float b = q_lane < k ? R.b : 0.f;
             dh[0] = mm16(R.wa[0], b, zero4());
@@ -197,11 +206,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             WS2_OPAQUE(ht, 66 + 8 * h); WS2_OPAQUE(gt, 67 + 8 * h);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * h);
-                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * h);
+                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * pi);
+                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * pi);
                 R.ar[c] = WS2_LDF(lds_g, (gt ^ (16 * c)) + 256 * c + 4096 * gbuf);
             }
-            float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
+            float* slab = d.s.DH1 + ((size_t)pi * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const float4 hv = R.hv[t];
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             const bool mine = n_lane >= off && n_lane < off + k;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (h == 0) dbs[0] += R.ar[c];       // (db2 of the four k <= 4 heads: all of columns 0 .. 15, once per tile)
+                if (pi == 0) dbs[0] += R.ar[c];       // (db2 of the four k <= 4 heads: all of columns 0 .. 15, once per tile)
                 const float a = mine ? R.ar[c] : 0.f;
 #ifndef WS2_X_NO_DW2
                 dws[0] = mm16(a, R.bt[0][c], dws[0]);
@@ -228,7 +237,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
     };
     // slots of the 48-row SH head: 0 reads | 1 - 3 dh1, 16 rows of W2 each | 4 mask, DH1, transposed reads | 5 - 7 dW2, 16 columns each
     auto sh_slot = [&](int slot, int tile, int gbuf, f32x4* dh, Rider& R) {
-        constexpr int h = FDGS_HEAD_SHS;
+        constexpr int pi = NH - 1;      // (the SH head is the last active one)
         auto read_dh1_operands = [&](int s) {
             int gn = o_gn, w2 = o_w2;
             WS2_OPAQUE(gn, 128 + 2 * s); WS2_OPAQUE(w2, 129 + 2 * s);
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             read_dh1_operands(0);
             int hn = o_hn;
             WS2_OPAQUE(hn, 140);
-            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * h); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * h);
+            R.hv[0] = WS2_LDF4(lds_h1, hn + 8192 * pi); R.hv[1] = WS2_LDF4(lds_h1, (hn ^ 64) + 8192 * pi);
         } else if (slot <= 3) {
             if (slot == 1) { dh[0] = zero4(); dh[1] = zero4(); }
             const float bb[4] = {R.bv.x, R.bv.y, R.bv.z, R.bv.w};
@@ -263,11 +272,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             WS2_OPAQUE(ht, 141);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * h);
-                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * h);
+                R.bt[0][c] = WS2_LDF(lds_h1, (ht ^ (16 * c)) + 128 * c + 8192 * pi);
+                R.bt[1][c] = WS2_LDF(lds_h1, (ht ^ (64 + 16 * c)) + 128 * c + 8192 * pi);
             }
             read_g_t(0);
-            float* slab = d.s.DH1 + ((size_t)h * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
+            float* slab = d.s.DH1 + ((size_t)pi * d.s.Npad + (size_t)tile * 16 + n_lane) * W + 32 * w + 4 * q_lane;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const float4 hv = R.hv[t];
@@ -389,7 +398,8 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             dma_g(nxt, it ^ 1); dma_hm(it ^ 1); dma_ri(nxt2, it);
             Rider R;
             // the first head's slots have no product to ride in (inside the previous tile's last product they cost 20 registers that are not there)
-            small_slot(0, 0, tile, it, dh_cur, R); small_slot(1, 0, tile, it, dh_cur, R); small_slot(2, 0, tile, it, dh_cur, R); small_slot(3, 0, tile, it, dh_cur, R);
+            constexpr int H0 = ws2_nth(HM, 0);
+            small_slot(0, H0, 0, tile, it, dh_cur, R); small_slot(1, H0, 0, tile, it, dh_cur, R); small_slot(2, H0, 0, tile, it, dh_cur, R); small_slot(3, H0, 0, tile, it, dh_cur, R);
             WS2_TICK(2);
             f32x4 acc[8];
 #pragma unroll
@@ -421,8 +431,11 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
 #endif
                         acc[to] = mm16(w1r[h][to][t][r], dh_cur[t][r], acc[to]);
                     }
-                    if (h + 1 < NH - 1) { if (grp < 4) small_slot(grp, h + 1, tile, it, dh_nxt, R); }
-                    else if (h + 1 == NH - 1) sh_slot(grp, tile, it, dh_nxt, R);
+                    // (h: position of the product's head; its rider is the head at position h + 1: the SH head's eight slots or a k <= 4 head's four)
+                    if (h + 1 < NH) {
+                        if (HAS_SH && h + 1 == NH - 1) sh_slot(grp, tile, it, dh_nxt, R);
+                        else if (grp < 4) small_slot(grp, ws2_nth(HM, h + 1 < NH ? h + 1 : 0), h + 1, tile, it, dh_nxt, R);
+                    }
                     if (prev >= 0) {
                         if (h == 0 && (grp == 4 || grp == 5)) finish_a(grp - 4);
                         if (h == 1 && grp == 4) finish_b();
@@ -463,20 +476,20 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
         for (int r = 0; r < 4; r++) {
             const int col = 4 * q + r;
             const int hd = col < 3 ? 0 : col < 6 ? 1 : col < 10 ? 2 : 3;
-            if (col <= 10 && dws[t][r] != 0.f) atomicAdd(&d.d_w2[hd][(size_t)(col - head_off(hd)) * W + f], dws[t][r]);
+            if (col <= 10 && ((HM >> hd) & 1) && dws[t][r] != 0.f) atomicAdd(&d.d_w2[hd][(size_t)(col - head_off(hd)) * W + f], dws[t][r]);
 #pragma unroll
             for (int og = 0; og < 3; og++)
-                if (dwh[og][t][r] != 0.f) atomicAdd(&d.d_w2[FDGS_HEAD_SHS][(size_t)(16 * og + col) * W + f], dwh[og][t][r]);
+                if (HAS_SH && dwh[og][t][r] != 0.f) atomicAdd(&d.d_w2[FDGS_HEAD_SHS][(size_t)(16 * og + col) * W + f], dwh[og][t][r]);
         }
     }
 #pragma unroll
     for (int gq = 0; gq < 4; gq++) dbs[gq] = sum_lane_groups(dbs[gq]);
     if (w == 0 && q == 0) {
         const int hd = n < 3 ? 0 : n < 6 ? 1 : n < 10 ? 2 : 3;
-        if (n <= 10 && dbs[0] != 0.f) atomicAdd(&d.d_b2[hd][n - head_off(hd)], dbs[0]);
+        if (n <= 10 && ((HM >> hd) & 1) && dbs[0] != 0.f) atomicAdd(&d.d_b2[hd][n - head_off(hd)], dbs[0]);
 #pragma unroll
         for (int og = 0; og < 3; og++)
-            if (dbs[1 + og] != 0.f) atomicAdd(&d.d_b2[FDGS_HEAD_SHS][16 * og + n], dbs[1 + og]);
+            if (HAS_SH && dbs[1 + og] != 0.f) atomicAdd(&d.d_b2[FDGS_HEAD_SHS][16 * og + n], dbs[1 + og]);
     }
 #ifdef FDGS_PROFILE_D2WS
     if (d.prof && lane == 0) {

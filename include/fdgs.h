@@ -49,7 +49,7 @@ int fdgs_timing_report(char* buf, size_t buflen, int reset);
  *   d1_form (16 | 32), d1_wgs, d1_split, skip_dead, d4_mfma, d4_rows_kb, tile_cull (0 = the reference's rectangle lists), rbwd_ppl (-1 = by image size | 4 | 2 | 0),
  *   tile_order (1 = the blending kernels take their tiles heaviest-first, 0 = image order), row_compact (1 = the deformation backward walks
  *   the non-zero rows instead of the non-zero 32-row tiles where it can; 2 = the same with the row lists built by the two-launch form),
- *   d2_form (0 = the weight-stationary backward-data kernel where it applies -- row lists, net_width 128, all five heads, C*L 32 or 48 --, 32 = the
+ *   d2_form (0 = the weight-stationary backward-data kernel where it applies -- row lists, net_width 128, C*L 32 or 48, five heads or position + scale + rotation --, 32 = the
  *   32-row kernel everywhere).
  * `name` is the lower- or upper-case knob name, with or without the FDGS_ prefix.  Process-global, not thread-safe against running calls:
  * set knobs between frames.  fdgs_tuning_reset restores the load-time values.  See INTEGRATION.md ("Knobs"). */
