@@ -71,13 +71,15 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {     
 // HM: the active heads (bit hd; at least three, the SH head -- if active -- last by construction of the head numbering).  Arrays per head are
 // indexed by the head's POSITION among the active ones (= its slab of saved activations / DH1, fdgs_deform_bwd's head_slot).
 __host__ __device__ constexpr int ws2_popc(int m) { return m == 0 ? 0 : (m & 1) + ws2_popc(m >> 1); }
-__host__ __device__ constexpr int ws2_nth(int m, int i, int hd = 0) { return (m & 1) ? (i == 0 ? hd : ws2_nth(m >> 1, i - 1, hd + 1)) : ws2_nth(m >> 1, i, hd + 1); }
+__host__ __device__ constexpr int ws2_nth(int m, int i, int hd = 0) { return m == 0 ? 0 : (m & 1) ? (i == 0 ? hd : ws2_nth(m >> 1, i - 1, hd + 1)) : ws2_nth(m >> 1, i, hd + 1); }
 
 template <int FU, int HM>
 __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
     constexpr int W = 128, NH = ws2_popc(HM), LDW = W + 4, XLD = W + 4, F = 16 * FU, PLD = F + 4;
     static_assert(NH >= 3 && HM < 32 && ws2_nth(HM, 0) != FDGS_HEAD_SHS, "three or more heads, a k <= 4 head first");
     constexpr bool HAS_SH = (HM >> FDGS_HEAD_SHS) & 1;
+    // (a TABLE of the active heads, evaluated here: called with a loop variable the recursion above is compiled, not folded -- a loop per call)
+    constexpr int HID[FDGS_NUM_HEADS] = {ws2_nth(HM, 0), ws2_nth(HM, 1), ws2_nth(HM, 2), ws2_nth(HM, 3), ws2_nth(HM, 4)};
     const fdgs_deform_params& p = d.p;
     // parks (LDS-DMA destinations, lane-linear 16-byte chunks, swizzled through the source addresses):
     //   h1 [head][wave]: chunk (row g, c8 = features 4 c8 .. + 3 of the wave's 32) at slot 8 g + (c8 ^ (g & 7))
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) w1r[h][to][t][r] = p.w1[ws2_nth(HM, h)][(size_t)(32 * w + 16 * t + 4 * q + r) * W + 16 * to + n];
+                for (int r = 0; r < 4; r++) w1r[h][to][t][r] = p.w1[HID[h]][(size_t)(32 * w + 16 * t + 4 * q + r) * W + 16 * to + n];
     // sums that live in registers for the whole launch: dW2 of the wave's 32 columns (D-lane (n, q) register r: row 4 q + r of the column
     // group, column 32 w + 16 t + n) -- the four k <= 4 heads share one group (their 11 rows ARE columns 0 .. 10 of G) -- and db2
     f32x4 dws[2] = {zero4(), zero4()}, dwh[3][2];
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
             dma_g(nxt, it ^ 1); dma_hm(it ^ 1); dma_ri(nxt2, it);
             Rider R;
             // the first head's slots have no product to ride in (inside the previous tile's last product they cost 20 registers that are not there)
-            constexpr int H0 = ws2_nth(HM, 0);
+            constexpr int H0 = HID[0];
             small_slot(0, H0, 0, tile, it, dh_cur, R); small_slot(1, H0, 0, tile, it, dh_cur, R); small_slot(2, H0, 0, tile, it, dh_cur, R); small_slot(3, H0, 0, tile, it, dh_cur, R);
             WS2_TICK(2);
             f32x4 acc[8];
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(256, 1) deform_bwd_data_ws_kernel(BwdDev d) {
                     // (h: position of the product's head; its rider is the head at position h + 1: the SH head's eight slots or a k <= 4 head's four)
                     if (h + 1 < NH) {
                         if (HAS_SH && h + 1 == NH - 1) sh_slot(grp, tile, it, dh_nxt, R);
-                        else if (grp < 4) small_slot(grp, ws2_nth(HM, h + 1 < NH ? h + 1 : 0), h + 1, tile, it, dh_nxt, R);
+                        else if (grp < 4) small_slot(grp, HID[h + 1 < NH ? h + 1 : 0], h + 1, tile, it, dh_nxt, R);
                     }
                     if (prev >= 0) {
                         if (h == 0 && (grp == 4 || grp == 5)) finish_a(grp - 4);

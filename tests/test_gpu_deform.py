@@ -578,4 +578,6 @@ def test_leftover_tiles_split_by_head_changes_nothing(cfg, n, monkeypatch):
     for a, b in zip(res["1"][1], res["0"][1]):
         assert (a is None) == (b is None)
         if a is not None:
-            assert torch.equal(a, b) or rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6     # (weight gradients: atomics in launch order)
+            # (weight gradients: float atomics in launch order -- two runs of the SAME backward differ by this much; measured up to 1.13e-6 on the
+            # second-layer weights, whose elements are sums over every row flushed by 256 workgroups)
+            assert torch.equal(a, b) or rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 5e-6
