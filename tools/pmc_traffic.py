@@ -16,7 +16,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALIAS = {"radix_digit_scan": "radix_scan", "scan_chunk": "scan_tiles", "scan_add": "scan_tiles", "adam": "adam_step",
-         "deform_plane_grad_mfma": "deform_plane_grad", "deform_fwd16": "deform_fwd", "deform_mlp_ws": "deform_fwd", "pack_weights16": "pack_weights"}
+         "deform_plane_grad_mfma": "deform_plane_grad", "deform_fwd16": "deform_fwd", "deform_mlp_ws": "deform_fwd", "deform_bwd_data_ws": "deform_bwd_data", "pack_weights16": "pack_weights"}
 
 
 def src_sha16():
